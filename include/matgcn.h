@@ -1,0 +1,163 @@
+/*
+ * matgcn.h - C ABI of the MI355X-native Multi-ATGCN forward hot path (libmatgcn.so).
+ *
+ * This is the drop-in boundary for ONE path of SonghuaHu-UMD/MultiSTGraph: MultiATGCN.forward()
+ * (reference libcity/model/traffic_flow_prediction/MultiATGCN.py:363-420) and the pieces it is
+ * made of.  The reference has no FFI of its own (it is 100 % Python/torch), so each entry point
+ * names the reference symbol it replaces; the Python class that binds them through ctypes is
+ * multistgraph_amd/model.py (the binding a maintainer would add is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns MATGCN_OK (0) or a negative matgcn_status; no exceptions, no
+ *     allocation, no implicit synchronisation: work is enqueued on the caller's hipStream_t
+ *     (passed as void*), and the caller owns every buffer including `prepared` and `workspace`.
+ *   - every pointer in matgcn_params / X / out / prepared / workspace is a DEVICE pointer to
+ *     contiguous row-major fp32, 16-byte aligned (torch allocations are 256-byte aligned).
+ *   - matgcn_dims is a plain host struct, read at call time.
+ *   - shapes use the reference's names: B batch, T = input_window (24), N nodes, H = rnn_units,
+ *     F = feature dim of batch['X'], K = stacked supports including the identity.
+ */
+#ifndef MATGCN_H
+#define MATGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MATGCN_ABI_VERSION 1
+
+typedef enum matgcn_status {
+  MATGCN_OK = 0,
+  MATGCN_ERR_NULL = -1,        /* a required pointer is NULL */
+  MATGCN_ERR_BAD_ARG = -2,     /* inconsistent / out-of-range dims */
+  MATGCN_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet */
+  MATGCN_ERR_SMALL_BUFFER = -4,/* prepared / workspace smaller than *_bytes() reports */
+  MATGCN_ERR_LAUNCH = -5       /* hipGetLastError() != hipSuccess after a launch */
+} matgcn_status;
+
+/* adaptive adjacency mode = config['adpadj'] (MultiATGCN.py:80-85) */
+enum { MATGCN_ADP_NONE = 0, MATGCN_ADP_UNI = 1, MATGCN_ADP_BI = 2 };
+
+#define MATGCN_MAX_LAYERS 4
+#define MATGCN_MAX_HEADS 8
+#define MATGCN_MAX_EXT 16
+
+typedef struct matgcn_dims {
+  int32_t batch;        /* B */
+  int32_t nodes;        /* N */
+  int32_t in_steps;     /* T = input_window; the reference hard-codes 24-step heads (:373-393) */
+  int32_t x_steps;      /* steps of batch['X'] = len_closeness+len_period+len_trend (96) */
+  int32_t x_feat;       /* F */
+  int32_t out_channels; /* output_window * output_dim = Conv2d out channels (:340) */
+  int32_t out_dim;      /* output_dim = end_dim - start_dim (:320) */
+  int32_t start_dim;    /* first flow channel of X (:365) */
+  int32_t hidden;       /* H = rnn_units; this build: 64 */
+  int32_t layers;       /* num_layers */
+  int32_t feat_in;      /* feature_final = out_dim + ext channels fed to layer 0 (:321) */
+  int32_t embed_dim;    /* d = node_emb columns */
+  int32_t adj_rank;     /* r = node_vec1 columns (unidirection) */
+  int32_t adp_mode;     /* MATGCN_ADP_* */
+  int32_t n_static;     /* first-order static supports used by the stack (0..3), (:87-93) */
+  int32_t cheb_k;       /* cheb_order (>= 2) */
+  int32_t scale_by_g;   /* 1 iff adjtype == 'multi': stack *= softmax(weights_g) (:102-103) */
+  int32_t n_heads;      /* temporal heads fused (2 if output_window < 6 else 4, :371-393) */
+  int32_t n_ts;         /* len(weight_tsg) = len_ts (:328-332) */
+  int32_t head_begin[MATGCN_MAX_HEADS]; /* first X step of head h (trend head never advances) */
+  int32_t ext_src[MATGCN_MAX_EXT];      /* X channel copied into encoder channel out_dim+j */
+} matgcn_dims;
+
+typedef struct matgcn_agcn_params { /* one AGCN (MultiATGCN.py:71-73) */
+  const float* weights_g;    /* (K,1,1) */
+  const float* weights_pool; /* (d, K, I, O) */
+  const float* bias_pool;    /* (d, O) */
+} matgcn_agcn_params;
+
+typedef struct matgcn_linear_params { /* one nn.Linear of the residual GRUCell (:139-140) */
+  const float* weight; /* (O, I) */
+  const float* bias;   /* (O) */
+} matgcn_linear_params;
+
+typedef struct matgcn_params { /* device pointers, names = the reference state_dict keys */
+  const float* node_emb;        /* (N, d) */
+  const float* node_vec1;       /* (N, r)  or NULL */
+  const float* node_vec2;       /* (r, N)  or NULL */
+  const float* static_supports; /* (n_static, N, N): model.supports[s][1] (:264-283) or NULL */
+  const float* weight_tsg;      /* (n_ts) */
+  const float* weight_ts[MATGCN_MAX_HEADS]; /* each (1,24,N,out_dim) */
+  const float* weights_gru;     /* encoder.weights_gru (L, T) */
+  matgcn_agcn_params gate[MATGCN_MAX_LAYERS];     /* encoder.agru_cells.l.gate   (O = 2H) */
+  matgcn_agcn_params update[MATGCN_MAX_LAYERS];   /* encoder.agru_cells.l.update (O = H)  */
+  matgcn_linear_params res_gate[MATGCN_MAX_LAYERS];   /* encoder.res_cells.l.gate   */
+  matgcn_linear_params res_update[MATGCN_MAX_LAYERS]; /* encoder.res_cells.l.update */
+  const float* end_conv_weight; /* (out_channels, T, 1, H) */
+  const float* end_conv_bias;   /* (out_channels) */
+} matgcn_params;
+
+/* ---- introspection ------------------------------------------------------------------------ */
+int matgcn_abi_version(void);
+const char* matgcn_error_string(int status);
+
+/* Bytes of the two caller-owned device buffers for `dims`. */
+int matgcn_prepared_bytes(const matgcn_dims* dims, size_t* bytes);
+int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes);
+
+/* Where the transposed support stack lives inside `prepared` (for tests / debugging):
+ * out[0] = float offset, out[1] = leading dimension, out[2] = padded node count Np,
+ * out[3] = number of non-identity supports Ks.  Element S_k[n][m] is at
+ * prepared[out[0] + m*out[1] + k*Np + n]. */
+int matgcn_supports_layout(const matgcn_dims* dims, int64_t out[4]);
+
+/* ---- parameter-only work, once per parameter update ----------------------------------------
+ * Replaces what AGCN.forward rebuilds on every call (MultiATGCN.py:78-105): the adaptive adjacency
+ * softmax(relu(E1 E2)) / softmax(relu(E E^T)), the Chebyshev support stack, the node-adaptive
+ * weights einsum('nd,dkio->nkio') and bias, with softmax(weights_g) folded into the weights; plus
+ * MFMA-fragment-ordered copies of the residual-GRU and Conv2d-head weights. */
+int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* prepared,
+                   size_t prepared_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the path ------------------------------------------------------------------------------
+ * MultiATGCN.forward / predict (MultiATGCN.py:363-420, eval mode, zero initial state):
+ * X (B, x_steps, N, F) -> out (B, output_window, N, output_dim). */
+int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                   const float* X, float* out, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- the pieces (same kernels, exposed for parity tests against the reference's modules) ----
+ * temporal-head fusion + channel concat (MultiATGCN.py:365-402): X -> x0 (B, T, N, feat_in) */
+int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, const float* X,
+                      float* x0, void* workspace, size_t workspace_bytes, void* stream);
+
+/* AGCN.forward of agru_cells[layer].gate on cat(x, h) (MultiATGCN.py:76-109):
+ * x (B,N,C_l), h (B,N,H) -> y (B,N,2H), no activation. */
+int matgcn_agcn_gate_fwd(const matgcn_dims* dims, const matgcn_params* params,
+                         const void* prepared, int layer, const float* x, const float* h,
+                         float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ATGRUCell.forward of agru_cells[layer] (MultiATGCN.py:120-128): x, h -> h_out (B,N,H) */
+int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params,
+                          const void* prepared, int layer, const float* x, const float* h,
+                          float* h_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* GRUCell.forward of res_cells[layer] (MultiATGCN.py:142-150): x, h -> h_out (B,N,H) */
+int matgcn_res_cell_fwd(const matgcn_dims* dims, const matgcn_params* params,
+                        const void* prepared, int layer, const float* x, const float* h,
+                        float* h_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ATGRUEncoder.forward (MultiATGCN.py:194-212): x0 (B,T,N,feat_in), h0 (L,B,N,H) or NULL (zeros)
+ * -> seq (B,T,N,H) of the last layer and finals (L,B,N,H); either output may be NULL. */
+int matgcn_encoder_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                       const float* x0, const float* h0, float* seq, float* finals,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* end_conv + reshape/permute (MultiATGCN.py:416-418, eval): seq (B,T,N,H) -> out */
+int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                       const float* seq, float* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATGCN_H */

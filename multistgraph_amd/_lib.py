@@ -1,0 +1,106 @@
+"""ctypes binding of libmatgcn.so (include/matgcn.h).  Fails loudly: there is no fallback.
+
+torch is imported first on purpose: libmatgcn.so needs libamdhip64.so.7 and must share the HIP
+runtime instance torch already loaded (same SONAME), so that torch's streams / device pointers are
+valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+MAX_LAYERS = 4
+MAX_HEADS = 8
+MAX_EXT = 16
+
+ADP_NONE, ADP_UNI, ADP_BI = 0, 1, 2
+ADP_CODES = {"none": ADP_NONE, "unidirection": ADP_UNI, "bidirection": ADP_BI}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmatgcn.so")
+
+
+class MatgcnError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "nodes", "in_steps", "x_steps", "x_feat", "out_channels", "out_dim", "start_dim",
+        "hidden", "layers", "feat_in", "embed_dim", "adj_rank", "adp_mode", "n_static", "cheb_k",
+        "scale_by_g", "n_heads", "n_ts")] + [
+        ("head_begin", C.c_int32 * MAX_HEADS),
+        ("ext_src", C.c_int32 * MAX_EXT),
+    ]
+
+
+class AgcnParams(C.Structure):
+    _fields_ = [("weights_g", C.c_void_p), ("weights_pool", C.c_void_p), ("bias_pool", C.c_void_p)]
+
+
+class LinearParams(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("node_emb", C.c_void_p), ("node_vec1", C.c_void_p), ("node_vec2", C.c_void_p),
+        ("static_supports", C.c_void_p), ("weight_tsg", C.c_void_p),
+        ("weight_ts", C.c_void_p * MAX_HEADS), ("weights_gru", C.c_void_p),
+        ("gate", AgcnParams * MAX_LAYERS), ("update", AgcnParams * MAX_LAYERS),
+        ("res_gate", LinearParams * MAX_LAYERS), ("res_update", LinearParams * MAX_LAYERS),
+        ("end_conv_weight", C.c_void_p), ("end_conv_bias", C.c_void_p),
+    ]
+
+
+# every symbol include/matgcn.h declares, with its argument types
+_P = C.c_void_p
+_SIGNATURES = {
+    "matgcn_abi_version": (C.c_int, []),
+    "matgcn_error_string": (C.c_char_p, [C.c_int]),
+    "matgcn_prepared_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
+    "matgcn_workspace_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
+    "matgcn_supports_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_int64 * 4)]),
+    "matgcn_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_fuse_heads": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_agcn_gate_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
+                                       C.c_size_t, _P]),
+    "matgcn_atgru_cell_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
+                                        C.c_size_t, _P]),
+    "matgcn_res_cell_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
+                                      C.c_size_t, _P]),
+    "matgcn_encoder_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, _P,
+                                     C.c_size_t, _P]),
+    "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmatgcn.so or raise; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MatgcnError(
+            "libmatgcn.so is not built (%s). Run `python -m multistgraph_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    if lib.matgcn_abi_version() != 1:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 1" % lib.matgcn_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().matgcn_error_string(status).decode()
+        raise MatgcnError("%s failed: %s (status %d)" % (what, msg, status))

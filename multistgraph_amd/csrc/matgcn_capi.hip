@@ -1,0 +1,600 @@
+// matgcn_capi.hip - host side of libmatgcn.so: the C ABI declared in include/matgcn.h.
+//
+// Pure launch orchestration: no allocation, no synchronisation, every kernel goes onto the caller's stream.
+// The call sequence of one forward mirrors MultiATGCN.forward (reference MultiATGCN.py:363-420) with the
+// parameter-only work hoisted into matgcn_prepare and the x-part of every graph convolution hoisted out of
+// the recurrence ("schedule").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/matgcn.h"
+#include "matgcn_internal.h"
+
+// single translation unit: the kernels are compiled together with their launchers
+#include "matgcn_kernels.hip"
+
+namespace {
+
+constexpr int H = 64;
+
+inline long rup(long v, long m) { return (v + m - 1) / m * m; }
+
+// ---- derived sizes ---------------------------------------------------------------------------------
+struct Plan {
+  int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od;
+  int nc0, nc0p;              // layer-0 plain-matrix columns (B*T*C0) and padded to 64
+  int NpC;                    // N rounded up to 64: plain N x N scratch leading dimension
+  // prepared offsets (floats)
+  long oSt, oPlainA, oPlainB, oPlainC;
+  long oWg[MATGCN_MAX_LAYERS], oWu[MATGCN_MAX_LAYERS], oWx[MATGCN_MAX_LAYERS], oBx[MATGCN_MAX_LAYERS];
+  long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
+  long wgStride[MATGCN_MAX_LAYERS], wuStride[MATGCN_MAX_LAYERS], wxStride;
+  int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], KxL[MATGCN_MAX_LAYERS];
+  long preparedFloats;
+  // workspace offsets (floats)
+  long oX0p, oX0m, oMX0, oXA0, oHx, oZHx, oG, oR, oSeq, oGX, oPX;
+  long seqStride;             // floats per layer sequence
+  long workspaceFloats;
+};
+
+int make_plan(const matgcn_dims* D, Plan* P) {
+  if (!D || !P) return MATGCN_ERR_NULL;
+  if (D->batch < 1 || D->nodes < 1 || D->layers < 1 || D->layers > MATGCN_MAX_LAYERS) return MATGCN_ERR_BAD_ARG;
+  if (D->hidden != H) return MATGCN_ERR_UNSUPPORTED;
+  if (D->in_steps < 1 || D->x_steps < D->in_steps || D->x_feat < 1) return MATGCN_ERR_BAD_ARG;
+  if (D->out_dim < 1 || D->out_channels < 1 || D->out_channels % D->out_dim) return MATGCN_ERR_BAD_ARG;
+  if (D->out_channels > 64) return MATGCN_ERR_UNSUPPORTED;
+  if (D->feat_in < D->out_dim || D->feat_in - D->out_dim > MATGCN_MAX_EXT || D->feat_in > 64) return MATGCN_ERR_BAD_ARG;
+  if (D->embed_dim < 1 || D->cheb_k < 2 || D->n_static < 0 || D->n_static > 3) return MATGCN_ERR_BAD_ARG;
+  if (D->adp_mode < 0 || D->adp_mode > 2) return MATGCN_ERR_BAD_ARG;
+  if (D->adp_mode == MATGCN_ADP_UNI && (D->adj_rank < 1 || D->adj_rank > 64)) return MATGCN_ERR_BAD_ARG;
+  if (D->adp_mode == MATGCN_ADP_BI && D->embed_dim > 64) return MATGCN_ERR_BAD_ARG;
+  if (D->n_heads < 1 || D->n_heads > MATGCN_MAX_HEADS || D->n_ts < D->n_heads || D->n_ts > MATGCN_MAX_HEADS)
+    return MATGCN_ERR_BAD_ARG;
+  for (int h = 0; h < D->n_heads; ++h)
+    if (D->head_begin[h] < 0 || D->head_begin[h] + D->in_steps > D->x_steps) return MATGCN_ERR_BAD_ARG;
+  for (int j = 0; j < D->feat_in - D->out_dim; ++j)
+    if (D->ext_src[j] < 0 || D->ext_src[j] >= D->x_feat) return MATGCN_ERR_BAD_ARG;
+  if (D->start_dim < 0 || D->start_dim + D->out_dim > D->x_feat) return MATGCN_ERR_BAD_ARG;
+  memset(P, 0, sizeof(*P));
+  P->B = D->batch; P->N = D->nodes; P->T = D->in_steps; P->L = D->layers; P->C0 = D->feat_in;
+  P->d = D->embed_dim; P->CH = D->out_channels; P->od = D->out_dim;
+  P->Np = (int)rup(P->N, 16);
+  P->NpC = (int)rup(P->N, 64);
+  P->nFirst = (D->adp_mode != MATGCN_ADP_NONE ? 1 : 0) + D->n_static;
+  if (P->nFirst < 1) return MATGCN_ERR_BAD_ARG;
+  P->Ks = P->nFirst * (D->cheb_k - 1);
+  P->Ktot = P->Ks + 1;
+  P->Mp = (int)rup((long)P->Ks * P->Np, 64);
+  P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 8);
+  P->NTc = (P->CH + 31) / 32;
+  P->nc0 = P->B * P->T * P->C0;
+  P->nc0p = (int)rup(P->nc0, 64);
+  long o = 0;
+  auto take = [&](long n) { long at = o; o += rup(n, 64); return at; };
+  P->oSt = take((long)P->Np * P->Mp);
+  const long plainN = (D->cheb_k > 2) ? (long)P->Np * P->NpC : 0;
+  P->oPlainA = take(plainN); P->oPlainB = take(plainN); P->oPlainC = take(plainN);
+  for (int l = 0; l < P->L; ++l) {
+    P->Cl[l] = (l == 0) ? P->C0 : H;
+    P->Cpad[l] = (int)rup(P->Cl[l], 8);
+    P->KxL[l] = (l == 0) ? P->Kx : 0;
+    const long kg = P->KxL[l] + (long)P->Ktot * H;
+    P->wgStride[l] = kg * 128;
+    P->wuStride[l] = kg * 64;
+    P->oWg[l] = take((long)P->N * P->wgStride[l]);
+    P->oWu[l] = take((long)P->N * P->wuStride[l]);
+    if (l > 0) {
+      P->wxStride = (long)P->Ktot * H * 192;
+      P->oWx[l] = take((long)P->N * P->wxStride);
+      P->oBx[l] = take((long)P->N * 192);
+    }
+    P->oRg[l] = take((long)(P->Cpad[l] + H) * 128);
+    P->oRu[l] = take((long)(P->Cpad[l] + H) * 64);
+  }
+  P->oHead = take((long)P->T * H * 32 * P->NTc);
+  P->preparedFloats = o;
+  // workspace
+  o = 0;
+  const long rowsBT = (long)P->B * P->T;
+  P->oX0p = take(rowsBT * P->Np * P->C0);
+  P->oX0m = take((long)P->Np * P->nc0p);
+  P->oMX0 = take((long)P->Mp * P->nc0p);
+  P->oXA0 = take((long)P->T * P->N * P->B * P->Kx);
+  P->oHx = take((long)P->B * P->Np * H);
+  P->oZHx = take((long)P->B * P->Np * H);
+  P->oG = take((long)P->N * P->B * P->Ks * H);
+  P->oR = take((long)P->N * P->B * H);
+  P->seqStride = rup(rowsBT * P->Np * H, 64);
+  P->oSeq = take(P->seqStride * P->L);
+  if (P->L > 1) {
+    P->oGX = take((long)P->N * rowsBT * P->Ks * H);
+    P->oPX = take((long)P->T * P->N * P->B * 192);
+  }
+  P->workspaceFloats = o;
+  return MATGCN_OK;
+}
+
+inline int launch_ok() { return hipGetLastError() == hipSuccess ? MATGCN_OK : MATGCN_ERR_LAUNCH; }
+#define CHECK_LAUNCH()                                   \
+  do {                                                   \
+    if (hipGetLastError() != hipSuccess) return MATGCN_ERR_LAUNCH; \
+  } while (0)
+#define RETURN_IF(x)            \
+  do {                          \
+    int rc__ = (x);             \
+    if (rc__ != MATGCN_OK) return rc__; \
+  } while (0)
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
+int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
+               float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s) {
+  MixArgs a;
+  a.St = St; a.ldS = P.Mp; a.X = X; a.xTileStride = xTileStride; a.ldX = ldX;
+  a.out = out; a.sN = sN; a.sK = sK; a.sT = sT;
+  a.Np = P.Np; a.N = P.N; a.Ks = Ks; a.nK = P.Np / 16; a.nColTiles = nColTiles;
+  a.nRowTiles = (int)(rup(rowsM, 64) / 64);
+  hipLaunchKernelGGL(k_mix, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
+  return launch_ok();
+}
+
+// mix of a [rows][Np][64] buffer into the node-major gather buffer G [N][rows][Ks][64]
+int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s) {
+  return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, (long)rows * P.Ks * H, H, (long)P.Ks * H, P.Ks,
+                    P.Ks * P.Np, s);
+}
+
+struct Ctx {
+  Plan P;
+  const matgcn_dims* D;
+  const matgcn_params* prm;
+  const float* prep;
+  float* ws;
+  hipStream_t s;
+};
+
+// x-part of layer l for `Tq` steps: folded rows (layer 0) or hoisted PX (layers >= 1).
+// xin: [B][Tq][Np][C_l] padded rows.
+int layer_prepass(const Ctx& c, int l, const float* xin, int Tq) {
+  const Plan& P = c.P;
+  const int rows = P.B * Tq;
+  const float* St = c.prep + P.oSt;
+  if (l == 0) {
+    const int ld = (int)rup((long)rows * P.C0, 64);
+    float* X0m = c.ws + P.oX0m;
+    float* MX0 = c.ws + P.oMX0;
+    hipLaunchKernelGGL(k_x0_to_matrix, dim3(blocks_for((size_t)P.Np * ld)), dim3(256), 0, c.s, xin, X0m, rows, P.Np,
+                       P.C0, ld);
+    CHECK_LAUNCH();
+    RETURN_IF(launch_mix(P, St, X0m, 64, ld, ld / 64, MX0, (long)ld, (long)P.Np * ld, 64, P.Ks, P.Ks * P.Np, c.s));
+    hipLaunchKernelGGL(k_build_xa0, dim3(blocks_for((size_t)Tq * P.N * P.B * P.Kx)), dim3(256), 0, c.s, xin, MX0,
+                       c.ws + P.oXA0, P.B, Tq, P.N, P.Np, P.C0, P.Ks, P.Kx, ld);
+    CHECK_LAUNCH();
+    return MATGCN_OK;
+  }
+  float* GX = c.ws + P.oGX;
+  RETURN_IF(mix_rows(P, St, xin, rows, GX, c.s));
+  NodeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ident = xin; a.identRowStride = (long)P.Np * H;
+  a.g = GX; a.Ks = P.Ks;
+  a.w = c.prep + P.oWx[l]; a.wNodeStride = P.wxStride;
+  a.rows = rows; a.N = P.N; a.Np = P.Np; a.T = Tq;
+  a.bias = c.prep + P.oBx[l];
+  a.pxOut = c.ws + P.oPX;
+  hipLaunchKernelGGL(k_px, dim3(P.N, (unsigned)((rows + 63) / 64)), dim3(256), 0, c.s, a);
+  return launch_ok();
+}
+
+// One ATGRU step of layer l at step t (of Tq): Hx <- cell(x_t, Hx); optional residual cell + blend.
+// raw: optional (B,N,128) dump of the gate pre-activation.
+int cell_step(const Ctx& c, int l, int t, int Tq, float* raw, bool gateOnly) {
+  const Plan& P = c.P;
+  const float* St = c.prep + P.oSt;
+  float* Hx = c.ws + P.oHx;
+  float* ZHx = c.ws + P.oZHx;
+  float* G = c.ws + P.oG;
+  float* R = c.ws + P.oR;
+  RETURN_IF(mix_rows(P, St, Hx, P.B, G, c.s));
+  NodeArgs a;
+  memset(&a, 0, sizeof(a));
+  if (l == 0) {
+    a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx;
+    a.xaNodeStride = (long)P.B * P.Kx; a.xaRowStride = P.Kx; a.xaLen = P.Kx;
+  } else {
+    a.px = c.ws + P.oPX + (size_t)t * P.N * P.B * 192;
+  }
+  a.ident = Hx; a.identRowStride = (long)P.Np * H;
+  a.g = G; a.Ks = P.Ks;
+  a.w = c.prep + P.oWg[l]; a.wNodeStride = P.wgStride[l];
+  a.rows = P.B; a.N = P.N; a.Np = P.Np; a.T = Tq;
+  a.raw = raw; a.zh = ZHx; a.r = R;
+  const dim3 grid(P.N, (unsigned)((P.B + 63) / 64));
+  hipLaunchKernelGGL(k_gate, grid, dim3(256), 0, c.s, a);
+  CHECK_LAUNCH();
+  if (gateOnly) return MATGCN_OK;
+  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, c.s));
+  a.ident = ZHx;
+  a.w = c.prep + P.oWu[l]; a.wNodeStride = P.wuStride[l];
+  a.raw = nullptr; a.zh = nullptr; a.hstate = Hx;
+  hipLaunchKernelGGL(k_update, grid, dim3(256), 0, c.s, a);
+  return launch_ok();
+}
+
+// residual GRU cell of layer l on (x_t, Hx) -> Hx (+ Seq_l[:, t]); blend == null gives the plain cell output
+int res_step(const Ctx& c, int l, const float* xt, long xRowStride, const float* blend, float* seq_t,
+             long seqRowStride) {
+  const Plan& P = c.P;
+  ResArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = xt; a.xRowStride = xRowStride; a.C = P.Cl[l]; a.Cpad = P.Cpad[l];
+  a.h = c.ws + P.oHx; a.hout = c.ws + P.oHx;
+  a.seq = seq_t; a.seqRowStride = seqRowStride;
+  a.wg = c.prep + P.oRg[l]; a.bg = c.prm->res_gate[l].bias;
+  a.wu = c.prep + P.oRu[l]; a.bu = c.prm->res_update[l].bias;
+  a.blend = blend;
+  a.B = P.B; a.N = P.N; a.Np = P.Np;
+  hipLaunchKernelGGL(k_res_gru, dim3(P.N, (unsigned)((P.B + 63) / 64)), dim3(256), 0, c.s, a);
+  return launch_ok();
+}
+
+int zero_async(float* p, long floats, hipStream_t s) {
+  return hipMemsetAsync(p, 0, (size_t)floats * sizeof(float), s) == hipSuccess ? MATGCN_OK : MATGCN_ERR_LAUNCH;
+}
+
+// the encoder over padded buffers: x0p [B][T][Np][C0] -> Seq[L-1]; finalsUser (L,B,N,H) optional
+int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* finalsUser) {
+  const Plan& P = c.P;
+  float* Hx = c.ws + P.oHx;
+  RETURN_IF(zero_async(c.ws + P.oZHx, (long)P.B * P.Np * H, c.s));
+  if (P.Np != P.N) {
+    for (int l = 0; l < P.L; ++l) {
+      const size_t cnt = (size_t)P.B * P.T * (P.Np - P.N) * H;
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for(cnt)), dim3(256), 0, c.s,
+                         c.ws + P.oSeq + l * P.seqStride, P.B * P.T, P.N, P.Np, H);
+      CHECK_LAUNCH();
+    }
+  }
+  for (int l = 0; l < P.L; ++l) {
+    const float* xin = (l == 0) ? x0p : c.ws + P.oSeq + (l - 1) * P.seqStride;
+    float* seq = c.ws + P.oSeq + l * P.seqStride;
+    RETURN_IF(layer_prepass(c, l, xin, P.T));
+    hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, c.s,
+                       h0User ? h0User + (size_t)l * P.B * P.N * H : nullptr, Hx, P.B, P.N, P.Np, H);
+    CHECK_LAUNCH();
+    const long xStep = (long)P.Np * P.Cl[l];
+    for (int t = 0; t < P.T; ++t) {
+      RETURN_IF(cell_step(c, l, t, P.T, nullptr, false));
+      RETURN_IF(res_step(c, l, xin + t * xStep, (long)P.T * xStep, c.prm->weights_gru + (size_t)l * P.T + t,
+                         seq + (size_t)t * P.Np * H, (long)P.T * P.Np * H));
+    }
+    if (finalsUser) {
+      hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, Hx,
+                         finalsUser + (size_t)l * P.B * P.N * H, P.B, P.N, P.Np, H);
+      CHECK_LAUNCH();
+    }
+  }
+  return MATGCN_OK;
+}
+
+int fuse_padded(const Ctx& c, const float* X, float* x0p) {
+  const Plan& P = c.P;
+  const matgcn_dims* D = c.D;
+  RETURN_IF(zero_async(x0p, (long)P.B * P.T * P.Np * P.C0, c.s));
+  FuseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = X; a.x0 = x0p; a.tsg = c.prm->weight_tsg;
+  for (int h = 0; h < D->n_heads; ++h) { a.ts[h] = c.prm->weight_ts[h]; a.headBegin[h] = D->head_begin[h]; }
+  for (int j = 0; j < P.C0 - P.od; ++j) a.extSrc[j] = D->ext_src[j];
+  a.B = P.B; a.T = P.T; a.N = P.N; a.Np = P.Np; a.C0 = P.C0; a.od = P.od; a.F = D->x_feat;
+  a.xSteps = D->x_steps; a.startDim = D->start_dim; a.nHeads = D->n_heads; a.nTs = D->n_ts;
+  hipLaunchKernelGGL(k_fuse_heads, dim3(blocks_for((size_t)P.B * P.T * P.N)), dim3(256), 0, c.s, a);
+  return launch_ok();
+}
+
+int head_padded(const Ctx& c, const float* seqp, float* out) {
+  const Plan& P = c.P;
+  HeadArgs a;
+  a.seq = seqp; a.w = c.prep + P.oHead; a.bias = c.prm->end_conv_bias; a.out = out;
+  a.B = P.B; a.T = P.T; a.N = P.N; a.Np = P.Np; a.CH = P.CH; a.od = P.od; a.NTc = P.NTc;
+  hipLaunchKernelGGL(k_head, dim3((unsigned)(P.B * ((P.N + 31) / 32))), dim3(64), 0, c.s, a);
+  return launch_ok();
+}
+
+int make_ctx(Ctx* c, const matgcn_dims* dims, const matgcn_params* params, const void* prepared, void* workspace,
+             size_t workspace_bytes, void* stream) {
+  if (!dims || !params || !workspace) return MATGCN_ERR_NULL;
+  RETURN_IF(make_plan(dims, &c->P));
+  if (workspace_bytes < (size_t)c->P.workspaceFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
+  c->D = dims; c->prm = params; c->prep = (const float*)prepared; c->ws = (float*)workspace;
+  c->s = (hipStream_t)stream;
+  return MATGCN_OK;
+}
+
+int check_layer_params(const matgcn_dims* D, const matgcn_params* p) {
+  if (!p->node_emb || !p->weights_gru) return MATGCN_ERR_NULL;
+  for (int l = 0; l < D->layers; ++l) {
+    if (!p->gate[l].weights_pool || !p->gate[l].bias_pool || !p->update[l].weights_pool || !p->update[l].bias_pool)
+      return MATGCN_ERR_NULL;
+    if (D->scale_by_g && (!p->gate[l].weights_g || !p->update[l].weights_g)) return MATGCN_ERR_NULL;
+    if (!p->res_gate[l].weight || !p->res_gate[l].bias || !p->res_update[l].weight || !p->res_update[l].bias)
+      return MATGCN_ERR_NULL;
+  }
+  return MATGCN_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int matgcn_abi_version(void) { return MATGCN_ABI_VERSION; }
+
+const char* matgcn_error_string(int status) {
+  switch (status) {
+    case MATGCN_OK: return "ok";
+    case MATGCN_ERR_NULL: return "required pointer is NULL";
+    case MATGCN_ERR_BAD_ARG: return "inconsistent or out-of-range dims";
+    case MATGCN_ERR_UNSUPPORTED: return "configuration not supported by this build";
+    case MATGCN_ERR_SMALL_BUFFER: return "prepared/workspace buffer too small";
+    case MATGCN_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown matgcn status";
+  }
+}
+
+int matgcn_prepared_bytes(const matgcn_dims* dims, size_t* bytes) {
+  if (!bytes) return MATGCN_ERR_NULL;
+  Plan P;
+  RETURN_IF(make_plan(dims, &P));
+  *bytes = (size_t)P.preparedFloats * sizeof(float);
+  return MATGCN_OK;
+}
+
+int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes) {
+  if (!bytes) return MATGCN_ERR_NULL;
+  Plan P;
+  RETURN_IF(make_plan(dims, &P));
+  *bytes = (size_t)P.workspaceFloats * sizeof(float);
+  return MATGCN_OK;
+}
+
+int matgcn_supports_layout(const matgcn_dims* dims, int64_t out[4]) {
+  if (!out) return MATGCN_ERR_NULL;
+  Plan P;
+  RETURN_IF(make_plan(dims, &P));
+  out[0] = P.oSt; out[1] = P.Mp; out[2] = P.Np; out[3] = P.Ks;
+  return MATGCN_OK;
+}
+
+int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* prepared, size_t prepared_bytes,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!prepared) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  const Plan& P = c.P;
+  if (prepared_bytes < (size_t)P.preparedFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
+  RETURN_IF(check_layer_params(dims, params));
+  if (dims->adp_mode == MATGCN_ADP_UNI && (!params->node_vec1 || !params->node_vec2)) return MATGCN_ERR_NULL;
+  if (dims->n_static > 0 && !params->static_supports) return MATGCN_ERR_NULL;
+  if (!params->end_conv_weight || !params->end_conv_bias) return MATGCN_ERR_NULL;
+  float* prep = (float*)prepared;
+  float* St = prep + P.oSt;
+  const int per = dims->cheb_k - 1;  // stack slots per first-order support
+  RETURN_IF(zero_async(St, (long)P.Np * P.Mp, c.s));
+  const bool cheb = dims->cheb_k > 2;
+  float* plainA = cheb ? prep + P.oPlainA : nullptr;  // T_{k-1}
+  float* plainB = cheb ? prep + P.oPlainB : nullptr;  // T_{k-2} / product scratch
+  float* plainC = cheb ? prep + P.oPlainC : nullptr;
+  if (cheb) {
+    RETURN_IF(zero_async(plainA, (long)P.Np * P.NpC, c.s));
+    RETURN_IF(zero_async(plainB, (long)P.Np * P.NpC, c.s));
+    RETURN_IF(zero_async(plainC, (long)P.Np * P.NpC, c.s));
+  }
+  const dim3 tgrid((unsigned)((P.N + 31) / 32), (unsigned)((P.N + 31) / 32));
+  for (int f = 0; f < P.nFirst; ++f) {
+    const int slot0 = f * per;
+    const int col0 = slot0 * P.Np;
+    const bool adaptive = (dims->adp_mode != MATGCN_ADP_NONE) && f == 0;
+    if (adaptive) {
+      const bool bi = dims->adp_mode == MATGCN_ADP_BI;
+      hipLaunchKernelGGL(k_adaptive_adj, dim3(P.N), dim3(256), 0, c.s, bi ? params->node_emb : params->node_vec1,
+                         bi ? nullptr : params->node_vec2, bi ? dims->embed_dim : dims->adj_rank, bi ? 1 : 0, P.N,
+                         St, P.Mp, col0, plainA, P.NpC);
+    } else {
+      const int sidx = f - (dims->adp_mode != MATGCN_ADP_NONE ? 1 : 0);
+      hipLaunchKernelGGL(k_static_transpose, tgrid, dim3(256), 0, c.s,
+                         params->static_supports + (size_t)sidx * P.N * P.N, P.N, St, P.Mp, col0, plainA, P.NpC);
+    }
+    CHECK_LAUNCH();
+    // Chebyshev orders 2..cheb_k-1 of this support: T_k = 2 S T_{k-1} - T_{k-2} (T_0 = I, T_1 = S).
+    // Three plain N x N buffers rotate; the product S.T_{k-1} is combined in place.
+    float* buf[3] = {plainA, plainB, plainC};
+    int iPrev1 = 0, iPrev2 = -1;
+    for (int k = 2; k < dims->cheb_k; ++k) {
+      const int iOut = (iPrev2 < 0) ? 1 : 3 - iPrev1 - iPrev2;
+      RETURN_IF(launch_mix(P, St + col0, buf[iPrev1], 64, P.NpC, P.NpC / 64, buf[iOut], (long)P.NpC, 0, 64, 1, P.Np,
+                           c.s));
+      hipLaunchKernelGGL(k_cheb_combine, tgrid, dim3(256), 0, c.s, buf[iOut], iPrev2 < 0 ? nullptr : buf[iPrev2],
+                         iPrev2 < 0 ? 1 : 0, P.N, P.NpC, St, P.Mp, (slot0 + k - 1) * P.Np, buf[iOut]);
+      CHECK_LAUNCH();
+      iPrev2 = iPrev1;
+      iPrev1 = iOut;
+    }
+  }
+  // node-adaptive weights
+  const unsigned N = (unsigned)P.N;
+  for (int l = 0; l < P.L; ++l) {
+    const int I = P.Cl[l] + H;
+    for (int part = 0; part < 2; ++part) {  // 0 gate (O=128), 1 update (O=64)
+      const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
+      const int O = part == 0 ? 128 : 64;
+      PrepAgcn a;
+      memset(&a, 0, sizeof(a));
+      a.E = params->node_emb; a.wpool = ap.weights_pool; a.bpool = ap.bias_pool;
+      a.wg = dims->scale_by_g ? ap.weights_g : nullptr;
+      a.d = P.d; a.Ktot = P.Ktot; a.I = I; a.O = O; a.OTsrc = O / 32;
+      // recurrent (h) part of the step stream
+      a.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
+      a.nodeStride = part == 0 ? P.wgStride[l] : P.wuStride[l];
+      a.OTdst = O / 32; a.otOfs = 0;
+      if (l == 0) {
+        a.mode = 1; a.Cw = P.C0; a.iOfs = 0; a.rows = P.Kx; a.streamOfs = 0;
+        hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
+        CHECK_LAUNCH();
+      }
+      a.mode = 0; a.Cw = H; a.iOfs = P.Cl[l]; a.rows = P.Ktot * H; a.streamOfs = (long)P.KxL[l] * O;
+      hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
+      CHECK_LAUNCH();
+      if (l > 0) {
+        // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row
+        a.out = prep + P.oWx[l]; a.nodeStride = P.wxStride; a.OTdst = 6; a.otOfs = part == 0 ? 0 : 4;
+        a.mode = 0; a.Cw = H; a.iOfs = 0; a.rows = P.Ktot * H; a.streamOfs = 0;
+        hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
+        CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, c.s, params->node_emb,
+                           ap.bias_pool, P.d, O, P.N, prep + P.oBx[l], 192, part == 0 ? 0 : 128);
+        CHECK_LAUNCH();
+      }
+    }
+    const int rowsR = P.Cpad[l] + H;
+    hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(rowsR / 8) * 4 * 64)), dim3(256), 0, c.s,
+                       params->res_gate[l].weight, I, 128, P.Cl[l], P.Cpad[l], rowsR, 4, prep + P.oRg[l]);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(rowsR / 8) * 2 * 64)), dim3(256), 0, c.s,
+                       params->res_update[l].weight, I, 64, P.Cl[l], P.Cpad[l], rowsR, 2, prep + P.oRu[l]);
+    CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.T * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
+                     params->end_conv_weight, P.T * H, P.CH, 0, 0, P.T * H, P.NTc, prep + P.oHead);
+  return launch_ok();
+}
+
+int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                   float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!prepared || !X || !out) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
+  for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
+  RETURN_IF(check_layer_params(dims, params));
+  const Plan& P = c.P;
+  float* x0p = c.ws + P.oX0p;
+  RETURN_IF(fuse_padded(c, X, x0p));
+  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  return head_padded(c, c.ws + P.oSeq + (P.L - 1) * P.seqStride, out);
+}
+
+int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, const float* X, float* x0,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!X || !x0) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, nullptr, workspace, workspace_bytes, stream));
+  if (!params->weight_tsg) return MATGCN_ERR_NULL;
+  for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
+  const Plan& P = c.P;
+  float* x0p = c.ws + P.oX0p;
+  RETURN_IF(fuse_padded(c, X, x0p));
+  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.T * P.N * P.C0)), dim3(256), 0, c.s, x0p, x0,
+                     P.B * P.T, P.N, P.Np, P.C0);
+  return launch_ok();
+}
+
+// shared by the three single-step entry points: stage x (B,N,C_l) as a one-step sequence and h as the state
+static int stage_single_step(const Ctx& c, int layer, const float* x, const float* h, float** xin_out) {
+  const Plan& P = c.P;
+  if (layer < 0 || layer >= P.L) return MATGCN_ERR_BAD_ARG;
+  // layer 0 stages into x0p, deeper layers into the (unused) first sequence buffer
+  float* xin = (layer == 0) ? c.ws + P.oX0p : c.ws + P.oSeq;
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * P.Cl[layer])), dim3(256), 0, c.s, x, xin, P.B,
+                     P.N, P.Np, P.Cl[layer]);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, c.s, h, c.ws + P.oHx, P.B,
+                     P.N, P.Np, H);
+  CHECK_LAUNCH();
+  RETURN_IF(zero_async(c.ws + P.oZHx, (long)P.B * P.Np * H, c.s));
+  *xin_out = xin;
+  return MATGCN_OK;
+}
+
+int matgcn_agcn_gate_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
+                         const float* x, const float* h, float* y, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  if (!prepared || !x || !h || !y) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  float* xin;
+  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
+  RETURN_IF(layer_prepass(c, layer, xin, 1));
+  return cell_step(c, layer, 0, 1, y, true);
+}
+
+int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
+                          const float* x, const float* h, float* h_out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!prepared || !x || !h || !h_out) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  const Plan& P = c.P;
+  float* xin;
+  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
+  RETURN_IF(layer_prepass(c, layer, xin, 1));
+  RETURN_IF(cell_step(c, layer, 0, 1, nullptr, false));
+  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
+                     P.B, P.N, P.Np, H);
+  return launch_ok();
+}
+
+int matgcn_res_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
+                        const float* x, const float* h, float* h_out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (!prepared || !x || !h || !h_out) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  const Plan& P = c.P;
+  float* xin;
+  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
+  RETURN_IF(res_step(c, layer, xin, (long)P.Np * P.Cl[layer], nullptr, nullptr, 0));
+  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
+                     P.B, P.N, P.Np, H);
+  return launch_ok();
+}
+
+int matgcn_encoder_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* x0,
+                       const float* h0, float* seq, float* finals, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  if (!prepared || !x0) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  RETURN_IF(check_layer_params(dims, params));
+  const Plan& P = c.P;
+  float* x0p = c.ws + P.oX0p;
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.T * P.Np * P.C0)), dim3(256), 0, c.s, x0, x0p,
+                     P.B * P.T, P.N, P.Np, P.C0);
+  CHECK_LAUNCH();
+  RETURN_IF(encoder_padded(c, x0p, h0, finals));
+  if (seq) {
+    hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.T * P.N * H)), dim3(256), 0, c.s,
+                       c.ws + P.oSeq + (P.L - 1) * P.seqStride, seq, P.B * P.T, P.N, P.Np, H);
+    CHECK_LAUNCH();
+  }
+  return MATGCN_OK;
+}
+
+int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* seq,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!prepared || !seq || !out) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  if (!params->end_conv_bias) return MATGCN_ERR_NULL;
+  const Plan& P = c.P;
+  float* seqp = c.ws + P.oSeq + (P.L - 1) * P.seqStride;
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.T * P.Np * H)), dim3(256), 0, c.s, seq, seqp,
+                     P.B * P.T, P.N, P.Np, H);
+  CHECK_LAUNCH();
+  return head_padded(c, seqp, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,731 @@
+// matgcn_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the Multi-ATGCN forward path.
+//
+// Every kernel cites the reference lines (libcity/model/traffic_flow_prediction/MultiATGCN.py) whose
+// arithmetic it implements.  All matrix contractions run on the exact-fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32): lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
+// the 16 accumulator registers of lane l hold C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+//
+// Data layout (all fp32, Np = N rounded up to 16, H = 64):
+//   St   [Np][Mp]            transposed support stack, column k*Np+n holds S_k[n][.]   (mix A operand)
+//   Hx   [rows][Np][64]      recurrent state / any per-row node features              (mix B operand)
+//   G    [N][rows][Ks][64]   graph-mixed features, node-major                          (node GEMM A operand)
+//   W*   [N][K/8][OT][64][4] node-adaptive weights in MFMA B-fragment order            (node GEMM B operand)
+//   PX   [T][N][B][192]      hoisted x-part of gate|update pre-activations (+bias)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "matgcn_internal.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// =================================================================================================
+// 1. support stack
+// =================================================================================================
+// Adaptive adjacency, one workgroup per row n (MultiATGCN.py:80-83):
+//   A[n][m] = softmax_m(relu(sum_r E1[n][r] * E2[r][m]))      (unidirection)
+//   A[n][m] = softmax_m(relu(sum_d E[n][d]  * E[m][d]))       (bidirection)
+// written transposed into St[m][col0 + n]; optionally also plain into P[n][ldP] (Chebyshev input).
+__global__ __launch_bounds__(256) void k_adaptive_adj(const float* __restrict__ e1, const float* __restrict__ e2,
+                                                      int rank, int bidir, int N, float* __restrict__ St, int ldS,
+                                                      int col0, float* __restrict__ plain, int ldP) {
+  __shared__ float red[256];
+  __shared__ float erow[64];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int r = tid; r < rank; r += 256) erow[r] = e1[(size_t)n * rank + r];
+  __syncthreads();
+  auto logit = [&](int m) {
+    float s = 0.f;
+    if (bidir) {
+      for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e1[(size_t)m * rank + r], s);
+    } else {
+      for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e2[(size_t)r * N + m], s);
+    }
+    return fmaxf(s, 0.f);
+  };
+  float mx = 0.f;  // relu output is >= 0
+  for (int m = tid; m < N; m += 256) mx = fmaxf(mx, logit(m));
+  red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int m = tid; m < N; m += 256) sum += expf(logit(m) - mx);
+  red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const float inv = 1.0f / red[0];
+  for (int m = tid; m < N; m += 256) {
+    const float p = expf(logit(m) - mx) * inv;
+    St[(size_t)m * ldS + col0 + n] = p;
+    if (plain) plain[(size_t)n * ldP + m] = p;
+  }
+}
+
+// static first-order supports (model.supports[s][1], MultiATGCN.py:269-283) -> transposed slots
+__global__ __launch_bounds__(256) void k_static_transpose(const float* __restrict__ S, int N, float* __restrict__ St,
+                                                          int ldS, int col0, float* __restrict__ plain, int ldP) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: m block, by: n block
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int n = by + j, m = bx + tx;
+    const float v = (n < N && m < N) ? S[(size_t)n * N + m] : 0.f;
+    tile[j][tx] = v;
+    if (plain && n < N && m < N) plain[(size_t)n * ldP + m] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int m = bx + j, n = by + tx;
+    if (m < N && n < N) St[(size_t)m * ldS + col0 + n] = tile[tx][j];
+  }
+}
+
+// Chebyshev recursion T_k = 2 S T_{k-1} - T_{k-2} (MultiATGCN.py:98-99): prod = S T_{k-1} comes from k_mix
+// (plain output); this kernel forms T_k, stores it transposed into its stack slot and plain for the next order.
+__global__ __launch_bounds__(256) void k_cheb_combine(const float* __restrict__ prod, const float* __restrict__ prev2,
+                                                      int prev2_is_identity, int N, int ldP, float* __restrict__ St,
+                                                      int ldS, int col0, float* __restrict__ plain_out) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int n = by + j, m = bx + tx;
+    float v = 0.f;
+    if (n < N && m < N) {
+      const float p2 = prev2_is_identity ? (n == m ? 1.f : 0.f) : prev2[(size_t)n * ldP + m];
+      v = 2.0f * prod[(size_t)n * ldP + m] - p2;
+      plain_out[(size_t)n * ldP + m] = v;
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int m = bx + j, n = by + tx;
+    if (m < N && n < N) St[(size_t)m * ldS + col0 + n] = tile[tx][j];
+  }
+}
+
+// =================================================================================================
+// 2. node-adaptive weights in MFMA fragment order
+// =================================================================================================
+// W[n][k][i][o] = g_k * sum_d E[n][d] * Wpool[d][k][i][o], bias[n][o] = sum_d E[n][d] * bpool[d][o]
+// (MultiATGCN.py:102-105; g = softmax(weights_g) is folded here instead of scaling the stack).
+// One thread produces the float4 a lane feeds to 4 consecutive MFMAs: rows j = 8*jg + 4*(lane>>5) + {0..3},
+// column o = 32*tile + (lane&31).
+__global__ __launch_bounds__(256) void k_prep_agcn(PrepAgcn a) {
+  const int n = blockIdx.y;
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  const int units = (a.rows >> 3) * a.OTsrc * 64;
+  if (unit >= units) return;
+  const int lane = unit & 63;
+  const int ot = (unit >> 6) % a.OTsrc;
+  const int jg = (unit >> 6) / a.OTsrc;
+  const int o = ot * 32 + (lane & 31);
+  const float* e = a.E + (size_t)n * a.d;
+  // softmax over the Ktot stack weights (tiny)
+  float gmax = -3.0e38f, gsum = 0.f;
+  if (a.wg) {
+    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
+    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
+  }
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = jg * 8 + 4 * (lane >> 5) + q;
+    float val = 0.f;
+    if (a.mode == 0) {
+      const int k = j / a.Cw, i = a.iOfs + (j - k * a.Cw);
+      if (k < a.Ktot) {
+        const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
+        const size_t dstride = (size_t)a.Ktot * a.I * a.O;
+        float s = 0.f;
+        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], wp[dd * dstride], s);
+        val = a.wg ? s * (expf(a.wg[k] - gmax) / gsum) : s;
+      }
+    } else {
+      const int nx = a.Ktot * a.Cw;  // folded x rows, then the bias row, then zero padding
+      if (j < nx) {
+        const int k = j / a.Cw, i = j - k * a.Cw;
+        const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
+        const size_t dstride = (size_t)a.Ktot * a.I * a.O;
+        float s = 0.f;
+        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], wp[dd * dstride], s);
+        val = a.wg ? s * (expf(a.wg[k] - gmax) / gsum) : s;
+      } else if (j == nx) {
+        float s = 0.f;
+        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], s);
+        val = s;
+      }
+    }
+    v[q] = val;
+  }
+  float* dst = a.out + (size_t)n * a.nodeStride + a.streamOfs +
+               ((size_t)(jg * a.OTdst + a.otOfs + ot) * 64 + lane) * 4;
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// bias[n][colOfs + o] = E[n] . bpool[:, o]   (hoisted-PX layers)
+__global__ __launch_bounds__(256) void k_prep_bias(const float* __restrict__ E, const float* __restrict__ bpool, int d,
+                                                   int O, int N, float* __restrict__ out, int ldo, int colOfs) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * O) return;
+  const int n = idx / O, o = idx - n * O;
+  float s = 0.f;
+  for (int dd = 0; dd < d; ++dd) s = fmaf(E[(size_t)n * d + dd], bpool[(size_t)dd * O + o], s);
+  out[(size_t)n * ldo + colOfs + o] = s;
+}
+
+// nn.Linear / Conv2d weight (O, I) -> fragment order [jg][OT][64][4] of B[j][o] = W[o][in(j)].
+// Rows j < Cpad map to input j (zero beyond C); rows j >= Cpad map to input C + (j - Cpad).
+__global__ __launch_bounds__(256) void k_prep_linear(const float* __restrict__ W, int I, int O, int C, int Cpad,
+                                                     int rows, int OT, float* __restrict__ out) {
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  const int units = (rows >> 3) * OT * 64;
+  if (unit >= units) return;
+  const int lane = unit & 63, ot = (unit >> 6) % OT, jg = (unit >> 6) / OT;
+  const int o = ot * 32 + (lane & 31);
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = jg * 8 + 4 * (lane >> 5) + q;
+    int in = -1;
+    if (j < Cpad) { if (j < C) in = j; } else { in = C + (j - Cpad); }
+    v[q] = (in >= 0 && in < I && o < O) ? W[(size_t)o * I + in] : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)unit * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// =================================================================================================
+// 3. layout helpers (all tiny, HBM-trivial)
+// =================================================================================================
+// user (rows, N, C) -> padded [rows][Np][C] (pad rows zero)
+__global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                   int N, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)rows * Np * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const int n = (idx / C) % Np;
+  const size_t r = idx / ((size_t)C * Np);
+  dst[idx] = (src && n < N) ? src[(r * N + n) * C + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rows(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                     int N, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)rows * N * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const int n = (idx / C) % N;
+  const size_t r = idx / ((size_t)C * N);
+  dst[idx] = src[(r * Np + n) * C + c];
+}
+
+// zero rows n in [N, Np) of a [rows][Np][C] buffer
+__global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ buf, int rows, int N, int Np, int C) {
+  const int per = (Np - N) * C;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)rows * per) return;
+  const size_t r = idx / per;
+  const int q = idx - r * per;
+  buf[(r * Np + N) * C + q] = 0.f;
+}
+
+// =================================================================================================
+// 4. temporal-head fusion prologue (MultiATGCN.py:365-402)
+// =================================================================================================
+// x0[b][t][n][c<od]  = sum_h softmax(weight_tsg)[h] * X[b][begin_h + t][n][start+c] * weight_ts[h][t][n][c]
+// x0[b][t][n][od+j]  = X[b][t][n][ext_src[j]]           (time of day / dynamic channels)
+__global__ __launch_bounds__(256) void k_fuse_heads(FuseArgs a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)a.B * a.T * a.N;
+  if (idx >= total) return;
+  const int n = idx % a.N;
+  const int t = (idx / a.N) % a.T;
+  const int b = idx / ((size_t)a.N * a.T);
+  float gmax = -3.0e38f, gsum = 0.f;
+  for (int h = 0; h < a.nTs; ++h) gmax = fmaxf(gmax, a.tsg[h]);
+  for (int h = 0; h < a.nTs; ++h) gsum += expf(a.tsg[h] - gmax);
+  float* dst = a.x0 + (((size_t)b * a.T + t) * a.Np + n) * a.C0;
+  for (int c = 0; c < a.od; ++c) {
+    float acc = 0.f;
+    for (int h = 0; h < a.nHeads; ++h) {
+      const float g = expf(a.tsg[h] - gmax) / gsum;
+      const float xv = a.X[(((size_t)b * a.xSteps + a.headBegin[h] + t) * a.N + n) * a.F + a.startDim + c];
+      const float wv = a.ts[h][((size_t)t * a.N + n) * a.od + c];
+      acc += g * xv * wv;
+    }
+    dst[c] = acc;
+  }
+  for (int j = 0; j < a.C0 - a.od; ++j)
+    dst[a.od + j] = a.X[(((size_t)b * a.xSteps + t) * a.N + n) * a.F + a.extSrc[j]];
+}
+
+// layer-0 encoder input as a plain matrix for the mix GEMM: X0m[m][(row*C0 + c)] = x0p[row][m][c]
+__global__ __launch_bounds__(256) void k_x0_to_matrix(const float* __restrict__ x0p, float* __restrict__ X0m, int rows,
+                                                      int Np, int C0, int ld) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)Np * ld;
+  if (idx >= total) return;
+  const int col = idx % ld;
+  const int m = idx / ld;
+  float v = 0.f;
+  if (col < rows * C0) {
+    const int row = col / C0, c = col - row * C0;
+    v = x0p[((size_t)row * Np + m) * C0 + c];
+  }
+  X0m[idx] = v;
+}
+
+// folded x-part of the layer-0 node GEMM: XA0[t][n][b][Kx] = [x0 (k=0) | mix_k(x0), k<Ks | 1.0 | 0...]
+// (the 1.0 column meets the bias row of the folded weights)
+__global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p, const float* __restrict__ MX0,
+                                                   float* __restrict__ XA0, int B, int T, int N, int Np, int C0,
+                                                   int Ks, int Kx, int ld) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)T * N * B * Kx;
+  if (idx >= total) return;
+  const int j = idx % Kx;
+  const int b = (idx / Kx) % B;
+  const int n = (idx / ((size_t)Kx * B)) % N;
+  const int t = idx / ((size_t)Kx * B * N);
+  const int row = b * T + t;
+  float v = 0.f;
+  const int nx = (Ks + 1) * C0;
+  if (j < C0) v = x0p[((size_t)row * Np + n) * C0 + j];
+  else if (j < nx) {
+    const int k = j / C0 - 1, c = j % C0;
+    v = MX0[((size_t)k * Np + n) * ld + (size_t)row * C0 + c];
+  } else if (j == nx) v = 1.0f;
+  XA0[idx] = v;
+}
+
+// =================================================================================================
+// 5. graph mix GEMM (MultiATGCN.py:106):  out[(k,n)][col] = sum_m S_k[n][m] * X[m][col]
+// =================================================================================================
+// 64 x 64 output tile per workgroup, 4 waves, each one 32x32 MFMA accumulator; K-step 16 staged through
+// LDS (register-prefetched double buffer, one barrier per step).  A = St (k-major, so the tile is 16 rows of
+// 256 contiguous bytes), B = 64 feature columns of one state row (256-byte lines).  Workgroups that share an
+// XCD (id % 8) sweep the row tiles of one column tile back to back, so St and that X slice stay in its L2.
+__global__ __launch_bounds__(256) void k_mix(MixArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][16 * 64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 64];
+  const int id = blockIdx.x;
+  int colTile, rowTile;
+  if ((a.nColTiles & 7) == 0) {
+    const int xcd = id & 7, j = id >> 3, cpx = a.nColTiles >> 3;
+    rowTile = j % a.nRowTiles;
+    colTile = xcd * cpx + j / a.nRowTiles;
+  } else {
+    rowTile = id % a.nRowTiles;
+    colTile = id / a.nRowTiles;
+  }
+  const int row0 = rowTile * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1, i = lane & 31, half = lane >> 5;
+  const int kk = tid >> 4, sg = tid & 15;
+  const float* ap = a.St + (size_t)kk * a.ldS + row0 + sg * 4;
+  const float* bp = a.X + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
+  float4 ra = *reinterpret_cast<const float4*>(ap);
+  float4 rb = *reinterpret_cast<const float4*>(bp);
+  *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = ra;
+  *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = rb;
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int it = 0; it < a.nK; ++it) {
+    const int cur = it & 1;
+    const bool more = (it + 1) < a.nK;
+    if (more) {
+      ra = *reinterpret_cast<const float4*>(ap + (size_t)(it + 1) * 16 * a.ldS);
+      rb = *reinterpret_cast<const float4*>(bp + (size_t)(it + 1) * 16 * a.ldX);
+    }
+    const float* A = &As[cur][half * 64 + wr * 32 + i];
+    const float* Bm = &Bs[cur][half * 64 + wc * 32 + i];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = MFMA32(A[s * 128], Bm[s * 128], acc);
+    if (more) {
+      *reinterpret_cast<float4*>(&As[cur ^ 1][kk * 64 + sg * 4]) = ra;
+      *reinterpret_cast<float4*>(&Bs[cur ^ 1][kk * 64 + sg * 4]) = rb;
+    }
+    __syncthreads();
+  }
+  float* obase = a.out + (size_t)colTile * a.sT + wc * 32 + i;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + wr * 32 + acc_row(r, half);
+    const int k = row / a.Np, n = row - k * a.Np;
+    if (k < a.Ks && n < a.N) obase[(size_t)n * a.sN + (size_t)k * a.sK] = acc[r];
+  }
+}
+
+// =================================================================================================
+// 6. node-wise contraction (MultiATGCN.py:108) - shared main loop
+// =================================================================================================
+// For one node n and a tile of 64 rows (batch items): acc[row][o] += sum_j A[row][j] * W_n[j][o], where the
+// reduction index j runs over up to three row segments (folded x-part | identity slot | Ks mixed slots).
+// A chunks of 64 rows x 32 are staged in LDS (row stride 36 floats: the ds_read_b128 of lane (row, half) is
+// conflict-free); the weight chunk is already in fragment order, so its LDS image is lane-linear.
+struct SegList {  // fields, not arrays: runtime-indexed arrays would live in scratch memory
+  const float *b0, *b1, *b2;
+  long st0, st1, st2;
+  int len0, len1, len2;
+};
+
+// chunk c (32 reduction indices, the last one of a segment may be shorter) -> source row base/stride, offset, groups
+__device__ __forceinline__ void decode_chunk(const SegList& S, int c, const float*& base, long& stride, int& off,
+                                             int& ng) {
+  const int n0 = (S.len0 + 31) >> 5, n1 = (S.len1 + 31) >> 5;
+  int len;
+  if (c < n0) { base = S.b0; stride = S.st0; len = S.len0; }
+  else if (c < n0 + n1) { c -= n0; base = S.b1; stride = S.st1; len = S.len1; }
+  else { c -= n0 + n1; base = S.b2; stride = S.st2; len = S.len2; }
+  off = c << 5;
+  const int rem = len - off;
+  ng = (rem >= 32 ? 32 : rem) >> 3;
+}
+
+#define AS_STRIDE 36
+
+template <int OT, int NT>
+__device__ __forceinline__ void node_mainloop(const SegList& S, int rowBase, int rowsTotal,
+                                              const float* __restrict__ wnode, int ot0, int bt, float* As,
+                                              float* Ws, f32x16 (&acc)[NT]) {
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+  const int total = ((S.len0 + 31) >> 5) + ((S.len1 + 31) >> 5) + ((S.len2 + 31) >> 5);
+  float4 ra[2], rw[OT];
+  int gofs = 0;
+  auto load = [&](int c) -> int {
+    const float* base;
+    long stride;
+    int off, ng;
+    decode_chunk(S, c, base, stride, off, ng);
+    const int per = ng * 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < 64 * per) {
+        const int row = idx / per, q = idx - row * per;
+        const int gr = rowBase + row;
+        if (gr < rowsTotal) v = *reinterpret_cast<const float4*>(base + (long)gr * stride + off + q * 4);
+      }
+      ra[u] = v;
+    }
+    const float4* wp = reinterpret_cast<const float4*>(wnode + (size_t)gofs * OT * 256);
+#pragma unroll
+    for (int u = 0; u < OT; ++u) {
+      const int idx = tid + 256 * u;
+      rw[u] = (idx < ng * OT * 64) ? wp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    gofs += ng;
+    return ng;
+  };
+  int ngCur = load(0);
+  for (int c = 0; c < total; ++c) {
+    {
+      const int per = ngCur * 2;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < 64 * per) {
+          const int row = idx / per, q = idx - row * per;
+          *reinterpret_cast<float4*>(&As[row * AS_STRIDE + q * 4]) = ra[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < OT; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < ngCur * OT * 64) *reinterpret_cast<float4*>(&Ws[idx * 4]) = rw[u];
+      }
+    }
+    __syncthreads();
+    int ngNext = 0;
+    if (c + 1 < total) ngNext = load(c + 1);
+    for (int g = 0; g < ngCur; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&As[(bt * 32 + i) * AS_STRIDE + g * 8 + half * 4]);
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const float4 w4 = *reinterpret_cast<const float4*>(&Ws[((g * OT + ot0 + tt) * 64 + lane) * 4]);
+        acc[tt] = MFMA32(a4.x, w4.x, acc[tt]);
+        acc[tt] = MFMA32(a4.y, w4.y, acc[tt]);
+        acc[tt] = MFMA32(a4.z, w4.z, acc[tt]);
+        acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
+      }
+    }
+    __syncthreads();
+    ngCur = ngNext;
+  }
+}
+
+__device__ __forceinline__ SegList make_segs(const NodeArgs& a, int n, const float* ident) {
+  SegList S;
+  // segment 0: folded x-part (may be empty), 1: identity slot, 2: the Ks mixed slots
+  S.b0 = a.xa ? a.xa + (size_t)n * a.xaNodeStride : nullptr;
+  S.st0 = a.xaRowStride;
+  S.len0 = a.xa ? a.xaLen : 0;
+  S.b1 = ident + (size_t)n * 64;
+  S.st1 = a.identRowStride;
+  S.len1 = 64;
+  S.b2 = a.g + (size_t)n * a.rows * a.Ks * 64;
+  S.st2 = (long)a.Ks * 64;
+  S.len2 = a.Ks * 64;
+  return S;
+}
+
+// ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) ------------------------------------------------------
+// zr = sigmoid(AGCN_gate([x|h])); z = zr[:, :H], r = zr[:, H:]; writes zh = z*h (next mix input) and r.
+__global__ __launch_bounds__(256) void k_gate(NodeArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Ws[4 * 4 * 64 * 4];
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
+  const int bt = w & 1, oh = w >> 1;
+  SegList S = make_segs(a, n, a.ident);
+  f32x16 acc[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+  node_mainloop<4, 2>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, oh * 2, bt, As, Ws, acc);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int o = (oh * 2 + tt) * 32 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = rowBase + bt * 32 + acc_row(r, half);
+      if (b >= a.rows) continue;
+      float v = acc[tt][r];
+      if (a.px) v += a.px[((size_t)n * a.rows + b) * 192 + o];
+      if (a.raw) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
+      const float s = sigmoid_f(v);
+      if (oh == 0) {
+        const size_t hi = ((size_t)b * a.Np + n) * 64 + o;
+        a.zh[hi] = s * a.ident[hi];
+      } else {
+        a.r[((size_t)n * a.rows + b) * 64 + (o - 64)] = s;
+      }
+    }
+  }
+}
+
+// ---- update AGCN + tanh + blend (MultiATGCN.py:125-127) ------------------------------------------------------
+// hc = tanh(AGCN_update([x|z*h])); h' = r*h + (1-r)*hc, written in place over h (each workgroup owns its rows).
+__global__ __launch_bounds__(256) void k_update(NodeArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Ws[4 * 2 * 64 * 4];
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
+  const int bt = w & 1, ot = w >> 1;
+  SegList S = make_segs(a, n, a.ident);  // ident = z*h here
+  f32x16 acc[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  node_mainloop<2, 1>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, ot, bt, As, Ws, acc);
+  const int o = ot * 32 + i;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = rowBase + bt * 32 + acc_row(r, half);
+    if (b >= a.rows) continue;
+    float v = acc[0][r];
+    if (a.px) v += a.px[((size_t)n * a.rows + b) * 192 + 128 + o];
+    const float hc = tanhf(v);
+    const float rr = a.r[((size_t)n * a.rows + b) * 64 + o];
+    const size_t hi = ((size_t)b * a.Np + n) * 64 + o;
+    const float h = a.hstate[hi];
+    a.hstate[hi] = rr * h + (1.0f - rr) * hc;
+  }
+}
+
+// ---- hoisted x-part for layers >= 1: PX[t][n][b][0:192] = bias[n] + [x | mix(x)] . Wx[n] ---------------------
+// Same contraction with M = B*T rows per node (rows are (b,t) pairs, b-major), O = 128 (gate) | 64 (update).
+__global__ __launch_bounds__(256) void k_px(NodeArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Ws[4 * 6 * 64 * 4];
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
+  const int bt = w & 1, oh = w >> 1;
+  SegList S = make_segs(a, n, a.ident);
+  f32x16 acc[3];
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+  node_mainloop<6, 3>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, oh * 3, bt, As, Ws, acc);
+  const int B = a.rows / a.T;
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt) {
+    const int o = (oh * 3 + tt) * 32 + i;
+    const float bias = a.bias[(size_t)n * 192 + o];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowBase + bt * 32 + acc_row(r, half);
+      if (row >= a.rows) continue;
+      const int b = row / a.T, t = row - b * a.T;
+      a.pxOut[(((size_t)t * a.N + n) * B + b) * 192 + o] = acc[tt][r] + bias;
+    }
+  }
+}
+
+// =================================================================================================
+// 7. residual GRU cell + per-step blend (MultiATGCN.py:142-150, 205-208)
+// =================================================================================================
+// Dense GRU with shared weights on [x_t | h'] rows of one node (64 batch rows per workgroup):
+//   zr = sigmoid([x|h'] Wg + bg); cand = [x | z*h']; hc = tanh(cand Wu + bu); res = r*h' + (1-r)*hc
+//   h'' = g*h' + (1-g)*res, g = sigmoid(weights_gru[l][t]).  h'' goes to the state and to Seq[l][:, t].
+// The A operand [64][Cpad+64] lives in LDS (row stride = 4*odd floats -> conflict-free b128 reads); the shared
+// weights are read from L2 straight into B fragments (lane-linear float4).
+__global__ __launch_bounds__(256) void k_res_gru(ResArgs a) {
+  // static LDS sized for Cpad <= 64 (68.6 KB; gfx950 allows up to 160 KB per workgroup)
+  __shared__ __attribute__((aligned(16))) float AR[64 * 132];  // [64][sr]   x | h'
+  __shared__ __attribute__((aligned(16))) float ZH[64 * 68];   // [64][68]   z*h'
+  __shared__ __attribute__((aligned(16))) float R2[64 * 68];   // [64][68]   r
+  const int K = a.Cpad + 64;
+  const int sr = K + 4;  // K is a multiple of 8, so (K+4)/4 is odd: conflict-free ds_read_b128 rows
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
+  const int bt = w & 1, oh = w >> 1;
+  // stage x (zero padded to Cpad) and h'
+  for (int idx = tid; idx < 64 * a.Cpad; idx += 256) {
+    const int row = idx / a.Cpad, c = idx - row * a.Cpad;
+    const int b = rowBase + row;
+    float v = 0.f;
+    if (b < a.B && c < a.C) v = a.x[((size_t)b * a.xRowStride) + (size_t)n * a.C + c];
+    AR[row * sr + c] = v;
+  }
+  for (int idx = tid; idx < 64 * 16; idx += 256) {
+    const int row = idx >> 4, q = idx & 15;
+    const int b = rowBase + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < a.B) v = *reinterpret_cast<const float4*>(a.h + ((size_t)b * a.Np + n) * 64 + q * 4);
+    *reinterpret_cast<float4*>(&AR[row * sr + a.Cpad + q * 4]) = v;
+  }
+  __syncthreads();
+  // GEMM 1: zr pre-activation, wave tile 32 rows x 64 cols
+  f32x16 acc[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+  const int ng = K >> 3;
+  for (int g = 0; g < ng; ++g) {
+    const float4 a4 = *reinterpret_cast<const float4*>(&AR[(bt * 32 + i) * sr + g * 8 + half * 4]);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const float4 w4 = *reinterpret_cast<const float4*>(a.wg + ((size_t)(g * 4 + oh * 2 + tt) * 64 + lane) * 4);
+      acc[tt] = MFMA32(a4.x, w4.x, acc[tt]);
+      acc[tt] = MFMA32(a4.y, w4.y, acc[tt]);
+      acc[tt] = MFMA32(a4.z, w4.z, acc[tt]);
+      acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int o = (oh * 2 + tt) * 32 + i;
+    const float bias = a.bg[o];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = bt * 32 + acc_row(r, half);
+      const float s = sigmoid_f(acc[tt][r] + bias);
+      if (oh == 0) ZH[row * 68 + o] = s * AR[row * sr + a.Cpad + o];
+      else R2[row * 68 + (o - 64)] = s;
+    }
+  }
+  __syncthreads();
+  // GEMM 2: candidate, wave tile 32 x 32 (wave w -> rows bt, cols oh*32)
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+  const int ngx = a.Cpad >> 3;
+  for (int g = 0; g < ng; ++g) {
+    const float* src = (g < ngx) ? &AR[(bt * 32 + i) * sr + g * 8 + half * 4]
+                                 : &ZH[(bt * 32 + i) * 68 + (g - ngx) * 8 + half * 4];
+    const float4 a4 = *reinterpret_cast<const float4*>(src);
+    const float4 w4 = *reinterpret_cast<const float4*>(a.wu + ((size_t)(g * 2 + oh) * 64 + lane) * 4);
+    acc2 = MFMA32(a4.x, w4.x, acc2);
+    acc2 = MFMA32(a4.y, w4.y, acc2);
+    acc2 = MFMA32(a4.z, w4.z, acc2);
+    acc2 = MFMA32(a4.w, w4.w, acc2);
+  }
+  const int o = oh * 32 + i;
+  const float bu = a.bu[o];
+  const float gate = a.blend ? sigmoid_f(a.blend[0]) : 0.f;  // g = sigmoid(weights_gru[l][t])
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = bt * 32 + acc_row(r, half);
+    const int b = rowBase + row;
+    if (b >= a.B) continue;
+    const float hc = tanhf(acc2[r] + bu);
+    const float hp = AR[row * sr + a.Cpad + o];
+    const float rr = R2[row * 68 + o];
+    const float res = rr * hp + (1.0f - rr) * hc;
+    const float hn = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
+    a.hout[((size_t)b * a.Np + n) * 64 + o] = hn;
+    if (a.seq) a.seq[((size_t)b * a.seqRowStride) + (size_t)n * 64 + o] = hn;
+  }
+}
+
+// state -> sequence copy used when the residual path is disabled in unit entry points (not on the hot path)
+__global__ __launch_bounds__(256) void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < count) dst[idx] = src[idx];
+}
+
+// =================================================================================================
+// 8. output head (MultiATGCN.py:416-418): Conv2d(T -> out*od, (1,H)) == [B*N x T*H] . [T*H x CH]
+// =================================================================================================
+// One wave per (b, 32-node tile); A fragments straight from the padded sequence (each lane walks its node's
+// 256-byte rows), B = fragment-ordered conv weight from L2.  out[b][o][n][dd] with channel ch = o*od + dd.
+__global__ __launch_bounds__(64) void k_head(HeadArgs a) {
+  const int tilesPerB = (a.N + 31) >> 5;
+  const int b = blockIdx.x / tilesPerB, n0 = (blockIdx.x % tilesPerB) * 32;
+  const int lane = threadIdx.x, i = lane & 31, half = lane >> 5;
+  const int node = min(n0 + i, a.Np - 1);  // pad rows are zero / in bounds
+  f32x16 acc[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+  const int nt = a.NTc;
+  for (int t = 0; t < a.T; ++t) {
+    const float* rowp = a.seq + (((size_t)b * a.T + t) * a.Np + node) * 64 + half * 4;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(rowp + g * 8);
+      const int jg = t * 8 + g;
+      for (int tt = 0; tt < nt; ++tt) {
+        const float4 w4 = *reinterpret_cast<const float4*>(a.w + ((size_t)(jg * nt + tt) * 64 + lane) * 4);
+        acc[tt] = MFMA32(a4.x, w4.x, acc[tt]);
+        acc[tt] = MFMA32(a4.y, w4.y, acc[tt]);
+        acc[tt] = MFMA32(a4.z, w4.z, acc[tt]);
+        acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
+      }
+    }
+  }
+  // accumulator rows = nodes, cols = channels
+  for (int tt = 0; tt < nt; ++tt) {
+    const int ch = tt * 32 + i;
+    if (ch >= a.CH) continue;
+    const float bias = a.bias[ch];
+    const int o = ch / a.od, dd = ch - o * a.od;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + acc_row(r, half);
+      if (n < a.N) a.out[(((size_t)b * (a.CH / a.od) + o) * a.N + n) * a.od + dd] = acc[tt][r] + bias;
+    }
+  }
+}

@@ -1,0 +1,228 @@
+"""Drop-in ``MultiATGCN`` plugin whose forward runs on the HIP hot path (libmatgcn.so).
+
+Mirrors the reference's model-plugin surface for this path - same class name, constructor
+signature, config / data_feature keys, parameter names and shapes (= checkpoint ABI), and the
+``forward / predict / calculate_loss`` methods the LibCity executor calls
+(reference libcity/model/traffic_flow_prediction/MultiATGCN.py:221-430,
+libcity/model/abstract_traffic_state_model.py:4-29).  The arithmetic of ``forward`` is NOT here:
+it is one call into the C ABI (include/matgcn.h); this module only owns parameters and plumbing.
+
+There is no CPU or PyTorch fallback: a CPU tensor, a missing library or an unsupported option
+raises.  See INTEGRATION.md for the one-line change that makes the reference's registry resolve
+this class.
+"""
+from __future__ import annotations
+
+import math
+from logging import getLogger
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import graph_prep
+from .ops import HotPath, PathSpec, spec_from_config
+
+try:  # inside a LibCity checkout: subclass the real plugin base so isinstance checks hold
+    from libcity.model.abstract_traffic_state_model import AbstractTrafficStateModel  # type: ignore
+except Exception:  # standalone: same two-level base (abstract_model.py:4-7, abstract_traffic_state_model.py:4-9)
+    class AbstractModel(nn.Module):
+        def __init__(self, config, data_feature):
+            nn.Module.__init__(self)
+
+        def predict(self, batch):
+            raise NotImplementedError
+
+        def calculate_loss(self, batch):
+            raise NotImplementedError
+
+    class AbstractTrafficStateModel(AbstractModel):
+        def __init__(self, config, data_feature):
+            self.data_feature = data_feature
+            super().__init__(config, data_feature)
+
+
+def masked_mae(preds: torch.Tensor, labels: torch.Tensor, null_val=float("nan"), min_s: float = 1e-4):
+    """loss.masked_mae_torch (reference libcity/model/loss.py:17-29), including its in-place
+    zeroing of small labels."""
+    labels[torch.abs(labels) < min_s] = 0
+    mask = ~torch.isnan(labels) if (isinstance(null_val, float) and math.isnan(null_val)) else labels.ne(null_val)
+    mask = mask.float()
+    mask = mask / torch.mean(mask)
+    mask = torch.where(torch.isnan(mask), torch.zeros_like(mask), mask)
+    loss = torch.abs(preds - labels) * mask
+    loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+    return torch.mean(loss)
+
+
+class _GraphConvParams(nn.Module):
+    """Parameter holder named like the reference AGCN (MultiATGCN.py:59-73)."""
+
+    def __init__(self, dim_in, dim_out, k_total, embed_dim):
+        super().__init__()
+        self.weights_g = nn.Parameter(torch.empty(k_total, 1, 1))
+        self.weights_pool = nn.Parameter(torch.empty(embed_dim, k_total, dim_in, dim_out))
+        self.bias_pool = nn.Parameter(torch.empty(embed_dim, dim_out))
+
+
+class _GraphCellParams(nn.Module):
+    """ATGRUCell parameter tree: .gate / .update (MultiATGCN.py:112-118)."""
+
+    def __init__(self, dim_in, hidden, k_total, embed_dim):
+        super().__init__()
+        self.gate = _GraphConvParams(dim_in + hidden, 2 * hidden, k_total, embed_dim)
+        self.update = _GraphConvParams(dim_in + hidden, hidden, k_total, embed_dim)
+
+
+class _DenseCellParams(nn.Module):
+    """Residual GRUCell parameter tree: two nn.Linear (MultiATGCN.py:134-140)."""
+
+    def __init__(self, dim_in, hidden):
+        super().__init__()
+        self.gate = nn.Linear(dim_in + hidden, 2 * hidden)
+        self.update = nn.Linear(dim_in + hidden, hidden)
+
+
+class _EncoderParams(nn.Module):
+    """ATGRUEncoder parameter tree (MultiATGCN.py:156-186)."""
+
+    def __init__(self, layers, in_steps, feat_in, hidden, k_total, embed_dim):
+        super().__init__()
+        self.agru_cells = nn.ModuleList()
+        self.res_cells = nn.ModuleList()
+        self.weights_gru = nn.Parameter(torch.empty(layers, in_steps))
+        for l in range(layers):
+            cin = feat_in if l == 0 else hidden
+            self.agru_cells.append(_GraphCellParams(cin, hidden, k_total, embed_dim))
+            self.res_cells.append(_DenseCellParams(cin, hidden))
+
+
+class MultiATGCN(AbstractTrafficStateModel):
+    def __init__(self, config, data_feature):
+        super().__init__(config, data_feature)
+        get = config.get
+        self.num_nodes = data_feature.get("num_nodes", 1)
+        self.input_window = get("input_window", 1)
+        self.output_window = get("output_window", 1)
+        self.add_time_in_day = get("add_time_in_day", False)
+        self.add_day_in_week = get("add_day_in_week", False)
+        self.node_specific_off = get("node_specific_off", False)
+        self.fnn_off = get("fnn_off", False)
+        self.gcn_off = get("gcn_off", False)
+        self.batch_size = get("batch_size", 64)
+        self.device = get("device", torch.device("cpu"))
+        config["num_nodes"] = self.num_nodes  # the reference writes this back (:233)
+        self.embed_dim_node = get("embed_dim_node", 10)
+        self.embed_dim_adj = get("embed_dim_adj", 10)
+        self.adpadj = get("adpadj", "bidirection")
+        self.adjtype = get("adjtype", "od")
+        self.cheb_order = get("cheb_order", 2)
+        self.start_dim = get("start_dim", 0)
+        self.end_dim = get("end_dim", 1)
+        self.load_dynamic = get("load_dynamic", False)
+        self.hidden_dim = get("rnn_units", 64)
+        self.num_layers = get("num_layers", 2)
+        assert self.num_layers >= 1, "At least one recurrent layer in the encoder"
+        if self.add_day_in_week and not self.add_time_in_day:
+            raise ValueError("add_day_in_week without add_time_in_day is undefined in the reference (:313-318)")
+        if data_feature.get("static", None) is not None:
+            raise NotImplementedError("add_static (PCA initial state, :286-296,:406-409) is not built yet: "
+                                      "pass static=None (DESIGN.md, out of scope this round)")
+        if self.gcn_off or self.fnn_off:
+            raise NotImplementedError("gcn_off / fnn_off ablation switches are not built yet (DESIGN.md)")
+        if self.input_window != 24:
+            raise ValueError("the reference fuses 24-step heads (:373-393): input_window must be 24")
+        if self.node_specific_off:
+            self.embed_dim_node = 1
+
+        # ---- one-off host graph prep (:238-283) -> first-order static supports (fp32, host)
+        mats = graph_prep.build_static_supports(data_feature.get("adj_mx"), data_feature.get("coordinate"),
+                                                None, self.adjtype)
+        use_static = self.adpadj == "none" or self.adjtype == "multi"  # (:87-93)
+        self._static_host = torch.from_numpy(np.stack(mats, 0)) if use_static else None
+        self._static_dev: Optional[torch.Tensor] = None
+
+        # ---- parameters, registered in the reference's order with the reference's names (:285-344)
+        n = self.num_nodes
+        rank = min(n, self.embed_dim_adj)  # torch.svd(adj)[..][:, :embed_dim_adj] (:299-304)
+        self.node_emb = nn.Parameter(torch.empty(n, self.embed_dim_node))
+        self.node_vec1 = nn.Parameter(torch.empty(n, rank))
+        self.node_vec2 = nn.Parameter(torch.empty(rank, n))
+        self.spec: PathSpec = spec_from_config(config, data_feature, n, rank,
+                                               0 if not use_static else len(mats))
+        self.output_dim = self.spec.out_dim
+        self.feature_final = self.spec.feat_in
+        self.len_ts = self.spec.n_ts
+        self.weight_ts = nn.ParameterList(
+            [nn.Parameter(torch.empty(1, 24, n, self.output_dim)) for _ in range(self.len_ts)])
+        self.weight_tsg = nn.Parameter(torch.empty(self.len_ts))
+        self.encoder = _EncoderParams(self.num_layers, self.input_window, self.feature_final, self.hidden_dim,
+                                      self.spec.k_total, self.embed_dim_node)
+        self.end_conv = nn.Conv2d(self.input_window, self.output_window * self.output_dim,
+                                  kernel_size=(1, self.hidden_dim), bias=True)
+        self._logger = getLogger()
+        self._scaler = data_feature.get("scaler")
+        self._init_parameters()
+        if self.node_specific_off:  # (:350-354)
+            self.node_emb = nn.Parameter(torch.ones(n, 1), requires_grad=False)
+        self._paths: Dict[int, HotPath] = {}
+        self._prepared_key = None
+        self.cache_prepared = True
+
+    def _init_parameters(self):
+        """xavier_uniform on every >=2-D parameter, U(0,1) on every 1-D one (:356-361)."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+            else:
+                nn.init.uniform_(p)
+
+    # ---- hot path plumbing ----------------------------------------------------------------------
+    def _state(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach() for k, v in self.named_parameters()}
+
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _path_for(self, x: torch.Tensor) -> HotPath:
+        if not x.is_cuda:
+            raise RuntimeError("MultiATGCN.forward runs on the HIP hot path only: batch['X'] is on %s. "
+                               "Move the model and the batch to the GPU (config['device'])." % x.device)
+        batch = x.shape[0]
+        hp = self._paths.get(batch)
+        if hp is None or hp.device != x.device:
+            hp = HotPath(self.spec, batch, x.device)
+            self._paths[batch] = hp
+            self._prepared_key = None
+        if self._static_host is not None and (self._static_dev is None or self._static_dev.device != x.device):
+            self._static_dev = self._static_host.to(x.device).contiguous()
+        key = (id(hp),) + self._params_key()
+        if key != self._prepared_key or not self.cache_prepared:
+            hp.bind(self._state(), self._static_dev)
+            hp.prepare()
+            self._prepared_key = key
+        return hp
+
+    # ---- the plugin surface the executor calls ---------------------------------------------------
+    def forward(self, batch):
+        x = batch["X"]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the HIP path implements forward only (backward kernels are the next scope row, DESIGN.md): "
+                "call predict()/calculate_loss() under torch.no_grad()")
+        assert x.shape[2] == self.num_nodes  # (:195)
+        if x.dtype != torch.float32:
+            x = x.float()
+        return self._path_for(x).forward(x.contiguous())
+
+    def predict(self, batch):
+        return self.forward(batch)
+
+    def calculate_loss(self, batch):
+        """de-scale prediction and label, masked MAE with null value 0 (:422-427)."""
+        y_true = batch["y"]
+        y_predicted = self.predict(batch)
+        y_true = self._scaler.inverse_transform(y_true[..., self.start_dim:self.end_dim])
+        y_predicted = self._scaler.inverse_transform(y_predicted)
+        return masked_mae(y_predicted, y_true, 0)

@@ -1,0 +1,286 @@
+"""Host-side handle on the HIP hot path: owns the device buffers and calls the C ABI.
+
+``PathSpec`` describes one model configuration (everything in matgcn_dims except the batch size);
+``HotPath`` binds a spec + batch size to a ``prepared`` and a ``workspace`` buffer and exposes one
+method per entry point of include/matgcn.h.  Tensors go in and out as torch CUDA tensors; only raw
+device pointers and the current HIP stream cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class PathSpec:
+    nodes: int
+    out_window: int
+    out_dim: int = 1
+    start_dim: int = 0
+    in_steps: int = 24
+    x_steps: int = 96
+    x_feat: int = 2
+    hidden: int = 64
+    layers: int = 2
+    feat_in: int = 2
+    embed_dim: int = 20
+    adj_rank: int = 20
+    adpadj: str = "unidirection"
+    adjtype: str = "multi"
+    cheb_k: int = 2
+    n_static: int = 3
+    head_begin: Sequence[int] = (0, 24, 48, 72)
+    n_ts: int = 4
+    ext_src: Sequence[int] = (1,)
+
+    @property
+    def scale_by_g(self) -> bool:
+        return self.adjtype == "multi"
+
+    @property
+    def n_first(self) -> int:
+        return (0 if self.adpadj == "none" else 1) + self.n_static
+
+    @property
+    def k_total(self) -> int:
+        return 1 + self.n_first * (self.cheb_k - 1)
+
+    def dims(self, batch: int) -> _lib.Dims:
+        d = _lib.Dims()
+        d.batch, d.nodes, d.in_steps, d.x_steps, d.x_feat = batch, self.nodes, self.in_steps, self.x_steps, self.x_feat
+        d.out_channels, d.out_dim, d.start_dim = self.out_window * self.out_dim, self.out_dim, self.start_dim
+        d.hidden, d.layers, d.feat_in = self.hidden, self.layers, self.feat_in
+        d.embed_dim, d.adj_rank = self.embed_dim, self.adj_rank
+        d.adp_mode = _lib.ADP_CODES[self.adpadj]
+        d.n_static, d.cheb_k, d.scale_by_g = self.n_static, self.cheb_k, int(self.scale_by_g)
+        d.n_heads, d.n_ts = len(self.head_begin), self.n_ts
+        for i, v in enumerate(self.head_begin):
+            d.head_begin[i] = int(v)
+        for i, v in enumerate(self.ext_src):
+            d.ext_src[i] = int(v)
+        return d
+
+
+def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_static: int) -> PathSpec:
+    """Derive the path description from the reference's config / data_feature keys
+    (MultiATGCN.py:224-235, 264-265, 310-332; head windows :371-393)."""
+    out_window = config.get("output_window", 1)
+    start_dim, end_dim = config.get("start_dim", 0), config.get("end_dim", 1)
+    od = end_dim - start_dim
+    tid = 0
+    if config.get("add_time_in_day", False):
+        tid = 8 if config.get("add_day_in_week", False) else 1
+    lc = data_feature.get("len_closeness", 0)
+    lp = data_feature.get("len_period", 0)
+    lt = data_feature.get("len_trend", 0)
+    heads: List[int] = []
+    for kk in range(lc // 24):
+        heads.append(24 * kk)
+    if lp > 0 and out_window >= 6:
+        for kk in range(lp // 24):
+            heads.append(lc + 24 * kk)
+    if lt > 0 and out_window >= 6:
+        for kk in range(lt // 24):
+            heads.append(lc + lp)  # the reference never advances the trend window (:389-393)
+    ext_dim = data_feature.get("ext_dim", 1)
+    x_feat = int(data_feature.get("feature_dim", od + ext_dim))
+    ext: List[int] = []
+    if config.get("add_time_in_day", False):
+        ext += [end_dim + j for j in range(tid)]
+    if config.get("load_dynamic", False):
+        ext += list(range(end_dim + tid, x_feat))
+    feat_in = od + ext_dim  # feature_final (:321); must equal od + len(ext) for cat() to line up
+    if feat_in != od + len(ext):
+        raise ValueError("feature_final=%d but forward() concatenates %d channels" % (feat_in, od + len(ext)))
+    node_specific_off = config.get("node_specific_off", False)
+    return PathSpec(
+        nodes=num_nodes, out_window=out_window, out_dim=od, start_dim=start_dim,
+        in_steps=config.get("input_window", 1), x_steps=lc + lp + lt, x_feat=x_feat,
+        hidden=config.get("rnn_units", 64), layers=config.get("num_layers", 2), feat_in=feat_in,
+        embed_dim=1 if node_specific_off else config.get("embed_dim_node", 10), adj_rank=adj_rank,
+        adpadj=config.get("adpadj", "bidirection"), adjtype=config.get("adjtype", "od"),
+        cheb_k=config.get("cheb_order", 2), n_static=n_static, head_begin=tuple(heads),
+        n_ts=int((lp + lt + lc) / 24), ext_src=tuple(ext))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check_tensor(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.MatgcnError("%s must live on the GPU: the hot path is HIP-only (no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise _lib.MatgcnError("%s must be float32, got %s" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.MatgcnError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t.contiguous()
+
+
+class HotPath:
+    """One (spec, batch) binding.  Not thread-safe; uses torch's current stream at call time."""
+
+    def __init__(self, spec: PathSpec, batch: int, device: torch.device):
+        self.lib = _lib.load()
+        self.spec, self.batch, self.device = spec, batch, torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MatgcnError("HotPath needs a GPU device, got %s" % self.device)
+        self.dims = spec.dims(batch)
+        nbytes = C.c_size_t()
+        _lib.check(self.lib.matgcn_prepared_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_prepared_bytes")
+        self.prepared = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.matgcn_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_workspace_bytes")
+        self.workspace = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        self.params = _lib.Params()
+        self._keep: List[torch.Tensor] = []
+        self._prepared_ok = False
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ws(self):
+        return C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel() * 4)
+
+    def bind(self, state: Dict[str, torch.Tensor], static_supports: Optional[torch.Tensor]):
+        """Point matgcn_params at the tensors of a reference-named state dict."""
+        s, p = self.spec, self.params
+        keep: List[torch.Tensor] = []
+
+        def dev(name, shape=None):
+            t = _check_tensor(state[name], name, shape)
+            keep.append(t)
+            return t.data_ptr()
+
+        n, d, h = s.nodes, s.embed_dim, s.hidden
+        p.node_emb = dev("node_emb", (n, d))
+        if s.adpadj == "unidirection":
+            p.node_vec1 = dev("node_vec1", (n, s.adj_rank))
+            p.node_vec2 = dev("node_vec2", (s.adj_rank, n))
+        else:
+            p.node_vec1 = p.node_vec2 = None
+        if s.n_static > 0:
+            st = _check_tensor(static_supports, "static_supports", (s.n_static, n, n))
+            keep.append(st)
+            p.static_supports = st.data_ptr()
+        else:
+            p.static_supports = None
+        p.weight_tsg = dev("weight_tsg", (s.n_ts,))
+        for i in range(len(s.head_begin)):
+            p.weight_ts[i] = dev("weight_ts.%d" % i, (1, 24, n, s.out_dim))
+        p.weights_gru = dev("encoder.weights_gru", (s.layers, s.in_steps))
+        kt = s.k_total
+        for l in range(s.layers):
+            cin = (s.feat_in if l == 0 else h) + h
+            for nm, o, dst in (("gate", 2 * h, p.gate), ("update", h, p.update)):
+                pre = "encoder.agru_cells.%d.%s." % (l, nm)
+                dst[l].weights_g = dev(pre + "weights_g", (kt, 1, 1))
+                dst[l].weights_pool = dev(pre + "weights_pool", (d, kt, cin, o))
+                dst[l].bias_pool = dev(pre + "bias_pool", (d, o))
+            for nm, o, dst in (("gate", 2 * h, p.res_gate), ("update", h, p.res_update)):
+                pre = "encoder.res_cells.%d.%s." % (l, nm)
+                dst[l].weight = dev(pre + "weight", (o, cin))
+                dst[l].bias = dev(pre + "bias", (o,))
+        p.end_conv_weight = dev("end_conv.weight", (s.out_window * s.out_dim, s.in_steps, 1, h))
+        p.end_conv_bias = dev("end_conv.bias", (s.out_window * s.out_dim,))
+        self._keep = keep
+        self._prepared_ok = False
+
+    # ---- entry points --------------------------------------------------------------------------
+    def prepare(self):
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_prepare(C.byref(self.dims), C.byref(self.params),
+                                           C.c_void_p(self.prepared.data_ptr()),
+                                           C.c_size_t(self.prepared.numel() * 4), ws, wsb, self._stream()),
+                   "matgcn_prepare")
+        self._prepared_ok = True
+
+    def _need_prepared(self):
+        if not self._prepared_ok:
+            self.prepare()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        s = self.spec
+        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        self._need_prepared()
+        out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_forward(C.byref(self.dims), C.byref(self.params),
+                                           C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward")
+        return out
+
+    def fuse_heads(self, x: torch.Tensor) -> torch.Tensor:
+        s = self.spec
+        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        out = torch.empty(self.batch, s.in_steps, s.nodes, s.feat_in, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_fuse_heads(C.byref(self.dims), C.byref(self.params), C.c_void_p(x.data_ptr()),
+                                              C.c_void_p(out.data_ptr()), ws, wsb, self._stream()),
+                   "matgcn_fuse_heads")
+        return out
+
+    def _single(self, fn, name, layer, x, h, out_cols):
+        s = self.spec
+        cl = s.feat_in if layer == 0 else s.hidden
+        x = _check_tensor(x, "x", (self.batch, s.nodes, cl))
+        h = _check_tensor(h, "h", (self.batch, s.nodes, s.hidden))
+        self._need_prepared()
+        out = torch.empty(self.batch, s.nodes, out_cols, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(fn(C.byref(self.dims), C.byref(self.params), C.c_void_p(self.prepared.data_ptr()), layer,
+                      C.c_void_p(x.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(out.data_ptr()), ws, wsb,
+                      self._stream()), name)
+        return out
+
+    def agcn_gate(self, layer, x, h):
+        return self._single(self.lib.matgcn_agcn_gate_fwd, "matgcn_agcn_gate_fwd", layer, x, h, 2 * self.spec.hidden)
+
+    def atgru_cell(self, layer, x, h):
+        return self._single(self.lib.matgcn_atgru_cell_fwd, "matgcn_atgru_cell_fwd", layer, x, h, self.spec.hidden)
+
+    def res_cell(self, layer, x, h):
+        return self._single(self.lib.matgcn_res_cell_fwd, "matgcn_res_cell_fwd", layer, x, h, self.spec.hidden)
+
+    def encoder(self, x0: torch.Tensor, h0: Optional[torch.Tensor] = None):
+        s = self.spec
+        x0 = _check_tensor(x0, "x0", (self.batch, s.in_steps, s.nodes, s.feat_in))
+        if h0 is not None:
+            h0 = _check_tensor(h0, "h0", (s.layers, self.batch, s.nodes, s.hidden))
+        self._need_prepared()
+        seq = torch.empty(self.batch, s.in_steps, s.nodes, s.hidden, dtype=torch.float32, device=self.device)
+        fin = torch.empty(s.layers, self.batch, s.nodes, s.hidden, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_encoder_fwd(C.byref(self.dims), C.byref(self.params),
+                                               C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x0.data_ptr()),
+                                               C.c_void_p(_ptr(h0)), C.c_void_p(seq.data_ptr()),
+                                               C.c_void_p(fin.data_ptr()), ws, wsb, self._stream()),
+                   "matgcn_encoder_fwd")
+        return seq, fin
+
+    def output_head(self, seq: torch.Tensor) -> torch.Tensor:
+        s = self.spec
+        seq = _check_tensor(seq, "seq", (self.batch, s.in_steps, s.nodes, s.hidden))
+        self._need_prepared()
+        out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_output_head(C.byref(self.dims), C.byref(self.params),
+                                               C.c_void_p(self.prepared.data_ptr()), C.c_void_p(seq.data_ptr()),
+                                               C.c_void_p(out.data_ptr()), ws, wsb, self._stream()),
+                   "matgcn_output_head")
+        return out
+
+    def supports(self) -> torch.Tensor:
+        """(Ks, N, N) un-transposed view of the support stack built by matgcn_prepare (tests)."""
+        self._need_prepared()
+        lay = (C.c_int64 * 4)()
+        _lib.check(self.lib.matgcn_supports_layout(C.byref(self.dims), C.byref(lay)), "matgcn_supports_layout")
+        off, ld, npad, ks = (int(v) for v in lay)
+        n = self.spec.nodes
+        st = self.prepared[off:off + npad * ld].view(npad, ld)
+        return torch.stack([st[:n, k * npad:k * npad + n].t() for k in range(ks)], 0).contiguous()
