@@ -1,0 +1,141 @@
+"""HIP hot path vs the reference's golden vectors and vs the CPU oracle, stage by stage.
+
+Everything here calls through the C ABI (multistgraph_amd.ops.HotPath -> libmatgcn.so).
+Tolerance: the north star's 1e-4 max-normalised fp32 for end-to-end outputs; single stages are held
+to 2e-5 (they differ from the reference only by fp32 summation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL, TINY, Case, max_norm_err
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 2e-5
+E2E_TOL = 1e-4
+
+
+def _path(c, lib_built):
+    from multistgraph_amd.ops import HotPath, spec_from_config
+    dev = torch.device("cuda:0")
+    use_static = c.adpadj == "none" or c.adjtype == "multi"
+    st = torch.from_numpy(c.gold["static_supports"]).to(dev) if use_static else None
+    spec = spec_from_config(c.config(), c.data_feature, c.n, min(c.n, 20), st.shape[0] if use_static else 0)
+    hp = HotPath(spec, c.b, dev)
+    hp.bind({k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}, st)
+    return hp, dev
+
+
+def _unscaled_stack(c, which):
+    """reference stack (K,N,N) with softmax(weights_g) divided out -> the raw non-identity supports"""
+    stack = c.gold["stack_l0_%s" % which].astype(np.float64)
+    if c.adjtype == "multi":
+        g = c.state["encoder.agru_cells.0.%s.weights_g" % which].reshape(-1).astype(np.float64)
+        g = np.exp(g - g.max())
+        g /= g.sum()
+        stack = stack / g[:, None, None]
+    return stack[1:]
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_support_stack(name, lib_built):
+    c = Case(name)
+    hp, _ = _path(c, lib_built)
+    got = hp.supports().cpu().numpy()
+    want = _unscaled_stack(c, "gate")
+    assert got.shape == want.shape
+    assert max_norm_err(got, want) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_fuse_heads(name, lib_built):
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    got = hp.fuse_heads(torch.from_numpy(c.x).to(dev)).cpu().numpy()
+    assert max_norm_err(got, c.gold["x0"]) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_agcn_gate(name, lib_built):
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    x, h = (torch.from_numpy(c.gold[k]).to(dev) for k in ("stage_x", "stage_h"))
+    got = hp.agcn_gate(0, x, h).cpu().numpy()
+    assert max_norm_err(got, c.gold["agcn_gate_l0"]) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_atgru_cells(name, lib_built):
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    x, h, x1 = (torch.from_numpy(c.gold[k]).to(dev) for k in ("stage_x", "stage_h", "stage_x1"))
+    assert max_norm_err(hp.atgru_cell(0, x, h).cpu().numpy(), c.gold["cell_l0"]) <= STAGE_TOL
+    assert max_norm_err(hp.atgru_cell(1, x1, h).cpu().numpy(), c.gold["cell_l1"]) <= STAGE_TOL
+    assert max_norm_err(hp.res_cell(0, x, h).cpu().numpy(), c.gold["res_l0"]) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_encoder_and_head(name, lib_built):
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    seq, fin = hp.encoder(torch.from_numpy(c.gold["x0"]).to(dev))
+    assert max_norm_err(seq.cpu().numpy(), c.gold["enc_seq"]) <= E2E_TOL
+    assert max_norm_err(fin.cpu().numpy(), c.gold["enc_finals"]) <= E2E_TOL
+    out = hp.output_head(torch.from_numpy(c.gold["enc_seq"]).to(dev)).cpu().numpy()
+    assert max_norm_err(out, c.gold["pred"]) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("name", TINY + FULL)
+def test_forward(name, lib_built):
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    got = hp.forward(torch.from_numpy(c.x).to(dev)).cpu().numpy()
+    assert got.shape == c.gold["pred"].shape
+    assert max_norm_err(got, c.gold["pred"]) <= E2E_TOL
+
+
+def test_encoder_nonzero_initial_state_vs_oracle(lib_built):
+    # h0 != 0 is not in the golden set: check against the oracle directly
+    from oracle import matgcn_oracle as O
+    c = Case("tiny_multi_uni_c2")
+    hp, dev = _path(c, lib_built)
+    rng = np.random.default_rng(5)
+    h0 = np.tanh(rng.standard_normal((2, c.b, c.n, 64))).astype(np.float32)
+    seq, fin = hp.encoder(torch.from_numpy(c.gold["x0"]).to(dev), torch.from_numpy(h0).to(dev))
+    p = O.to_tensors(c.state)
+    st = O.supports_as_tensors(c.gold["static_supports"])
+    want_seq, want_fin = O.encoder(torch.from_numpy(c.gold["x0"]), torch.from_numpy(h0), p, st, c.adjtype, c.adpadj,
+                                   c.cheb, 2, faithful=False)
+    assert max_norm_err(seq.cpu().numpy(), want_seq.numpy()) <= E2E_TOL
+    assert max_norm_err(fin.cpu().numpy(), torch.stack(want_fin, 0).numpy()) <= E2E_TOL
+
+
+@pytest.mark.parametrize("batch", [1, 5, 64, 70])
+def test_ragged_batches_vs_oracle(batch, lib_built):
+    # batch sizes around the 64-row tile of the node-wise contraction, N not a multiple of 16
+    from multistgraph_amd import synthetic as syn
+    from oracle import matgcn_oracle as O
+    c = Case("tiny_multi_uni_c2")
+    c.b = batch
+    c.x, c.y = syn.make_batch_arrays(batch, c.n, c.out, 77, feat=c.feat)
+    hp, dev = _path(c, lib_built)
+    got = hp.forward(torch.from_numpy(c.x).to(dev)).cpu().numpy()
+    p = O.to_tensors(c.state)
+    st = O.supports_as_tensors(c.gold["static_supports"])
+    want = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful=False).numpy()
+    assert max_norm_err(got, want) <= E2E_TOL
+
+
+def test_linearity_of_graph_mix(lib_built):
+    # size-independent property at the Baltimore shape: the gate pre-activation is affine in (x, h):
+    # f(a) + f(b) - f(0) == f(a + b)
+    c = Case("bm403_out24")
+    hp, dev = _path(c, lib_built)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    xa, xb = (torch.randn(c.b, c.n, 2, generator=g).to(dev) for _ in range(2))
+    ha, hb = (torch.randn(c.b, c.n, 64, generator=g).to(dev) for _ in range(2))
+    z = hp.agcn_gate(0, torch.zeros_like(xa), torch.zeros_like(ha))
+    lhs = hp.agcn_gate(0, xa, ha) + hp.agcn_gate(0, xb, hb) - z
+    rhs = hp.agcn_gate(0, xa + xb, ha + hb)
+    assert max_norm_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= 1e-5
