@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py - forward throughput of the Multi-ATGCN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one MultiATGCN.predict() of one synthetic batch already resident in HBM.  Workload at
+every N: the configuration BASELINE.json's metric is quoted on - Baltimore, 403 nodes, 24 h -> 24 h,
+adjtype=multi + adpadj=unidirection (K = 5 supports), B = 64 per GPU, fp32 (exact f32 MFMA; the 1e-4
+parity tolerance of the north star is an fp32 tolerance).  Batches shard over ranks with no data-path
+collective (forward needs none), so scaling is weak: value = all ranks' B*T*N node-steps / max-over-ranks
+time.  Parameter-only work (support stack, node-adaptive weights: matgcn_prepare) is redone inside
+every timed step, as the reference redoes it in every forward.
+
+Rank 0 prints ONE JSON line.  Two extra objects:
+  roofline     - the dominant kernel (k_mix, the graph-mix GEMM): algorithmic FLOPs per launch divided by
+                 its average launch duration measured with HIP events in situ (one extra instrumented
+                 forward after the timed region), against the dense fp32 MFMA peak.
+  cpu_baseline - the CPU oracle in its reference-faithful order (oracle/, kind "port"), timed on this
+                 host's cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_TBS = 8.0
+
+WORKLOADS = {
+    # name: nodes, per-GPU batch, out window, city
+    "bm403": dict(nodes=403, batch=64, out=24, city="BM",
+                  desc="Baltimore 403-node, in=24h out=24h, batch=64/GPU, multi+unidirection K=5"),
+    "dc237": dict(nodes=237, batch=64, out=12, city="DC",
+                  desc="DC 237-node, in=24h out=12h, batch=64/GPU, multi+unidirection K=5"),
+}
+
+
+def algorithmic_flops_per_unit(n, k_total=5, c0=2, h=64, out=24):
+    """SURVEY.md section 8d / BASELINE.md section 4."""
+    total = 0.0
+    for i_l in (c0 + h, 2 * h):
+        total += 4 * (k_total - 1) * n * i_l + 6 * k_total * i_l * h + 6 * i_l * h
+    return total + 2 * h * out
+
+
+def algorithmic_bytes_per_unit(c0=2, h=64, elem=4):
+    return elem * ((2 * c0 + 7 * h) + (2 * h + 7 * h))
+
+
+def build_model(w, device, seed):
+    from multistgraph_amd import synthetic as syn
+    from multistgraph_amd.model import MultiATGCN
+    df = syn.make_data_feature(w["nodes"], seed, w["city"])
+    cfg = dict(input_window=24, output_window=w["out"], add_time_in_day=True, add_day_in_week=False,
+               load_dynamic=False, adjtype="multi", adpadj="unidirection", cheb_order=2, embed_dim_node=20,
+               embed_dim_adj=20, rnn_units=64, num_layers=2, device=device, batch_size=w["batch"])
+    torch.manual_seed(seed)
+    model = MultiATGCN(cfg, df).to(device).eval()   # reference init law: xavier / U(0,1)
+    return model, df, cfg
+
+
+def cpu_baseline(w, seed, x_np, model_state, df, pred_gpu):
+    """Reference-faithful CPU oracle on the same workload; ~10-30 s of CPU work."""
+    from oracle import matgcn_oracle as O
+    p = {k: v.detach().cpu() for k, v in model_state.items()}
+    st = O.supports_as_tensors(O.static_supports(df["adj_mx"], df["coordinate"], None, "multi"))
+    cfg = dict(adjtype="multi", adpadj="unidirection", cheb_order=2, num_layers=2, rnn_units=64,
+               len_closeness=48, len_period=24, len_trend=24, output_window=w["out"], input_window=24,
+               add_time_in_day=True, add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=1)
+    xb = torch.from_numpy(x_np)
+    with torch.no_grad():
+        O.forward(xb[:4], p, st, cfg, faithful=True)          # warm-up (small)
+        t0 = time.perf_counter()
+        pred = O.forward(xb, p, st, cfg, faithful=True)
+        dt = time.perf_counter() - t0
+    units = x_np.shape[0] * 24 * w["nodes"]
+    err = float((pred - pred_gpu.cpu()).abs().max() / pred.abs().max())
+    return dict(value=units / dt, unit="node-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 reference-faithful oracle forward of the full workload (B=%d, N=%d) after a B=4 warm-up; "
+                       "%.2f s on %d torch threads" % (x_np.shape[0], w["nodes"], dt, torch.get_num_threads()),
+                seconds=dt, gpu_vs_cpu_max_norm_err=err), pred
+
+
+def in_situ_kernel_times(model, batch):
+    """One instrumented forward: HIP events around every kernel launch of the path, on its stream."""
+    from multistgraph_amd import _lib
+    lib = _lib.load()
+    cap = 4096
+    _lib.check(lib.matgcn_profile_enable(63, cap), "matgcn_profile_enable")
+    with torch.no_grad():
+        model.predict(batch)
+    torch.cuda.synchronize()
+    ms = (C.c_float * cap)()
+    kinds = (C.c_int * cap)()
+    cnt = C.c_int()
+    _lib.check(lib.matgcn_profile_collect(ms, kinds, cap, C.byref(cnt)), "matgcn_profile_collect")
+    lib.matgcn_profile_disable()
+    out = {}
+    for i in range(cnt.value):
+        out.setdefault(_lib.PROF_KINDS[kinds[i]], []).append(float(ms[i]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="bm403", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache-prepared", action="store_true",
+                    help="keep matgcn_prepare out of the timed steps (inference with frozen weights)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from multistgraph_amd import build as mbuild
+    from multistgraph_amd import synthetic as syn
+    if rank == 0:
+        mbuild.build(verbose=False)
+    if distributed:
+        dist.barrier()
+
+    w = dict(WORKLOADS[args.workload])
+    if args.batch:
+        w["batch"] = args.batch
+    seed = 0
+    model, df, cfg = build_model(w, device, seed)
+    model.cache_prepared = bool(args.cache_prepared)
+    x_np, y_np = syn.make_batch_arrays(w["batch"], w["nodes"], w["out"], seed + rank, feat=2)
+    batch = {"X": torch.from_numpy(x_np).to(device), "y": torch.from_numpy(y_np).to(device)}
+
+    def sync_all():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            pred = model.predict(batch)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pred = model.predict(batch)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    units_per_step = w["batch"] * 24 * w["nodes"] * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = units_per_step / (elapsed / args.steps)
+
+    result = None
+    if rank == 0:
+        flops_unit = algorithmic_flops_per_unit(w["nodes"], out=w["out"])
+        fwd_tflops = flops_unit * w["batch"] * 24 * w["nodes"] / (ms_per_step * 1e-3) / 1e12
+        times = in_situ_kernel_times(model, batch)
+        mix = times.get("k_mix", [])
+        n, b, ks, h = w["nodes"], w["batch"], 4, 64
+        # launch order per layer: 1 hoisted pre-pass launch, then 2 in-step launches (h, z*h) per time step;
+        # the roofline line is about the in-step launches (columns = B*64)
+        prepass = {l * (1 + 2 * 24) for l in range(2)}
+        step_mix = [m for i, m in enumerate(mix) if i not in prepass]
+        mix_ms = statistics.mean(step_mix) if step_mix else float("nan")
+        mix_flops = 2.0 * ks * n * n * b * h                       # algorithmic, unpadded
+        achieved = mix_flops / (mix_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="k_mix", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
+                        unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS, traffic=None,
+                        launches=len(step_mix), avg_launch_ms=mix_ms,
+                        flops_per_launch=mix_flops,
+                        whole_forward=dict(algorithmic_tflops=fwd_tflops,
+                                           frac_mfma=fwd_tflops / PEAK_MFMA_F32_TFLOPS,
+                                           algorithmic_gbs=algorithmic_bytes_per_unit() * units_per_step / world /
+                                           (ms_per_step * 1e-3) / 1e9,
+                                           flops_per_unit=flops_unit),
+                        kernel_ms_per_forward={k: round(sum(v), 4) for k, v in times.items()})
+        ytrue = batch["y"][..., 0:1].clone()
+        from multistgraph_amd.model import masked_mae
+        mae12 = float(masked_mae(pred[:, min(12, w["out"]) - 1], ytrue[:, min(12, w["out"]) - 1]).item())
+        result = {
+            "metric": "forward node-steps/s (B*T*N per second), MultiATGCN.predict",
+            "value": value, "unit": "node-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "nodes": w["nodes"], "per_gpu_batch": w["batch"],
+                       "global_batch": w["batch"] * world, "in_steps": 24, "out_steps": w["out"],
+                       "parallelism": "batch shards, no data-path collective (dp%d)" % world,
+                       "prepare_in_timed_region": not args.cache_prepared},
+            "mae_at_12": mae12,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, pred_cpu = cpu_baseline(w, seed, x_np, dict(model.named_parameters()), df, pred)
+            result["cpu_baseline"] = base
+            result["mae_at_12_cpu"] = float(masked_mae(pred_cpu[:, min(12, w["out"]) - 1],
+                                                       torch.from_numpy(y_np)[:, min(12, w["out"]) - 1, :, 0:1]).item())
+            result["gpu_over_cpu"] = value / base["value"]
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

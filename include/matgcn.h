@@ -157,6 +157,18 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
                        const float* seq, float* out, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- measurement hooks (bench.py; not on the hot path) ---------------------------------------
+ * Time individual kernel launches in situ with HIP events recorded on the caller's stream.
+ * enable() creates 2*max_launches events (the only allocation in the library, outside any forward)
+ * and selects which kernels are bracketed (bit mask of MATGCN_PROF_*); while enabled every selected
+ * launch records an event pair until max_launches is reached.  collect() synchronises the recorded
+ * events and writes per-launch milliseconds and kernel kinds; disable() destroys the events. */
+enum { MATGCN_PROF_MIX = 1, MATGCN_PROF_GATE = 2, MATGCN_PROF_UPDATE = 4, MATGCN_PROF_RES = 8,
+       MATGCN_PROF_PX = 16, MATGCN_PROF_HEAD = 32, MATGCN_PROF_ALL = 63 };
+int matgcn_profile_enable(int kind_mask, int max_launches);
+int matgcn_profile_collect(float* ms, int* kinds, int capacity, int* count);
+int matgcn_profile_disable(void);
+
 #ifdef __cplusplus
 }
 #endif

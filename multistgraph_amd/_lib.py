@@ -74,7 +74,11 @@ _SIGNATURES = {
     "matgcn_encoder_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, _P,
                                      C.c_size_t, _P]),
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
+    "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    "matgcn_profile_disable": (C.c_int, []),
 }
+PROF_KINDS = {1: "k_mix", 2: "k_gate", 4: "k_update", 8: "k_res_gru", 16: "k_px", 32: "k_head"}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None

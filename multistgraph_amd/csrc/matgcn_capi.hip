@@ -116,6 +116,29 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   return MATGCN_OK;
 }
 
+// ---- optional in-situ launch timing (matgcn_profile_*) ------------------------------------------------
+struct Prof {
+  int mask = 0, cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;
+  int* kinds = nullptr;
+};
+Prof g_prof;
+
+struct ProfScope {  // records an event pair around one launch when that kernel kind is selected
+  hipStream_t s;
+  int slot = -1;
+  ProfScope(int kind, hipStream_t stream) : s(stream) {
+    if ((g_prof.mask & kind) && g_prof.used < g_prof.cap) {
+      slot = g_prof.used++;
+      g_prof.kinds[slot] = kind;
+      (void)hipEventRecord(g_prof.ev[2 * slot], s);
+    }
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  }
+};
+
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? MATGCN_OK : MATGCN_ERR_LAUNCH; }
 #define CHECK_LAUNCH()                                   \
   do {                                                   \
@@ -137,6 +160,7 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   a.out = out; a.sN = sN; a.sK = sK; a.sT = sT;
   a.Np = P.Np; a.N = P.N; a.Ks = Ks; a.nK = P.Np / 16; a.nColTiles = nColTiles;
   a.nRowTiles = (int)(rup(rowsM, 64) / 64);
+  ProfScope prof(MATGCN_PROF_MIX, s);
   hipLaunchKernelGGL(k_mix, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
   return launch_ok();
 }
@@ -185,6 +209,7 @@ int layer_prepass(const Ctx& c, int l, const float* xin, int Tq) {
   a.rows = rows; a.N = P.N; a.Np = P.Np; a.T = Tq;
   a.bias = c.prep + P.oBx[l];
   a.pxOut = c.ws + P.oPX;
+  ProfScope prof(MATGCN_PROF_PX, c.s);
   hipLaunchKernelGGL(k_px, dim3(P.N, (unsigned)((rows + 63) / 64)), dim3(256), 0, c.s, a);
   return launch_ok();
 }
@@ -213,14 +238,20 @@ int cell_step(const Ctx& c, int l, int t, int Tq, float* raw, bool gateOnly) {
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.T = Tq;
   a.raw = raw; a.zh = ZHx; a.r = R;
   const dim3 grid(P.N, (unsigned)((P.B + 63) / 64));
-  hipLaunchKernelGGL(k_gate, grid, dim3(256), 0, c.s, a);
+  {
+    ProfScope prof(MATGCN_PROF_GATE, c.s);
+    hipLaunchKernelGGL(k_gate, grid, dim3(256), 0, c.s, a);
+  }
   CHECK_LAUNCH();
   if (gateOnly) return MATGCN_OK;
   RETURN_IF(mix_rows(P, St, ZHx, P.B, G, c.s));
   a.ident = ZHx;
   a.w = c.prep + P.oWu[l]; a.wNodeStride = P.wuStride[l];
   a.raw = nullptr; a.zh = nullptr; a.hstate = Hx;
-  hipLaunchKernelGGL(k_update, grid, dim3(256), 0, c.s, a);
+  {
+    ProfScope prof(MATGCN_PROF_UPDATE, c.s);
+    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, c.s, a);
+  }
   return launch_ok();
 }
 
@@ -237,6 +268,7 @@ int res_step(const Ctx& c, int l, const float* xt, long xRowStride, const float*
   a.wu = c.prep + P.oRu[l]; a.bu = c.prm->res_update[l].bias;
   a.blend = blend;
   a.B = P.B; a.N = P.N; a.Np = P.Np;
+  ProfScope prof(MATGCN_PROF_RES, c.s);
   hipLaunchKernelGGL(k_res_gru, dim3(P.N, (unsigned)((P.B + 63) / 64)), dim3(256), 0, c.s, a);
   return launch_ok();
 }
@@ -300,6 +332,7 @@ int head_padded(const Ctx& c, const float* seqp, float* out) {
   HeadArgs a;
   a.seq = seqp; a.w = c.prep + P.oHead; a.bias = c.prm->end_conv_bias; a.out = out;
   a.B = P.B; a.T = P.T; a.N = P.N; a.Np = P.Np; a.CH = P.CH; a.od = P.od; a.NTc = P.NTc;
+  ProfScope prof(MATGCN_PROF_HEAD, c.s);
   hipLaunchKernelGGL(k_head, dim3((unsigned)(P.B * ((P.N + 31) / 32))), dim3(64), 0, c.s, a);
   return launch_ok();
 }
@@ -595,6 +628,41 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
                      P.B * P.T, P.N, P.Np, H);
   CHECK_LAUNCH();
   return head_padded(c, seqp, out);
+}
+
+int matgcn_profile_disable(void) {
+  if (g_prof.ev) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    delete[] g_prof.kinds;
+  }
+  g_prof = Prof();
+  return MATGCN_OK;
+}
+
+int matgcn_profile_enable(int kind_mask, int max_launches) {
+  if (max_launches < 1 || max_launches > (1 << 20)) return MATGCN_ERR_BAD_ARG;
+  matgcn_profile_disable();
+  g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
+  g_prof.kinds = new int[max_launches];
+  for (int i = 0; i < 2 * max_launches; ++i)
+    if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return MATGCN_ERR_LAUNCH;
+  g_prof.cap = max_launches;
+  g_prof.mask = kind_mask;
+  return MATGCN_OK;
+}
+
+int matgcn_profile_collect(float* ms, int* kinds, int capacity, int* count) {
+  if (!ms || !count) return MATGCN_ERR_NULL;
+  const int n = g_prof.used < capacity ? g_prof.used : capacity;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return MATGCN_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MATGCN_ERR_LAUNCH;
+    if (kinds) kinds[i] = g_prof.kinds[i];
+  }
+  *count = n;
+  g_prof.used = 0;
+  return MATGCN_OK;
 }
 
 }  // extern "C"

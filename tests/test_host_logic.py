@@ -1,0 +1,112 @@
+"""CPU-side checks: host graph prep, the plugin's parameter tree, config -> path description,
+and that libmatgcn.so builds, loads and exports every symbol include/matgcn.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL, TINY, Case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", TINY[:6] + FULL[:2])
+def test_graph_prep_matches_reference(name):
+    from multistgraph_amd import graph_prep
+    c = Case(name)
+    mats = graph_prep.build_static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], None, c.adjtype)
+    assert np.abs(np.stack(mats, 0) - c.gold["static_supports"]).max() <= 1e-6
+
+
+def test_graph_prep_unsorted_geo_ids():
+    # the reference pivots on geo_id, i.e. distances follow sorted ids whatever the row order
+    from multistgraph_amd import graph_prep, synthetic as syn
+    co = syn.make_coordinates(9, 3)
+    perm = np.random.default_rng(0).permutation(9)
+    shuffled = co.iloc[perm].reset_index(drop=True)
+    a = graph_prep.haversine_km(graph_prep.lonlat_table(co))
+    b = graph_prep.haversine_km(graph_prep.lonlat_table(shuffled))
+    assert np.allclose(a, b)
+
+
+@pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_od_non_c3", "tiny_multi_non_c3", "tiny_multi_uni_dyn7",
+                                  "dc237_out12"])
+def test_parameter_tree_is_the_checkpoint_abi(name):
+    from multistgraph_amd.model import MultiATGCN
+    c = Case(name)
+    m = MultiATGCN(c.config(), c.data_feature)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(got) == list(c.shapes)          # same names, same registration order
+    assert got == {k: tuple(v) for k, v in c.shapes.items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+    # the reference init law: xavier for >= 2-D, U(0,1) for 1-D
+    m2 = MultiATGCN(c.config(), c.data_feature)
+    assert 0.0 <= float(m2.weight_tsg.min()) and float(m2.weight_tsg.max()) <= 1.0
+    bound = (6.0 / (c.n + 20)) ** 0.5
+    assert float(m2.node_emb.abs().max()) <= bound + 1e-6
+
+
+def test_spec_from_config_heads_and_channels():
+    from multistgraph_amd.ops import spec_from_config
+    c = Case("tiny_multi_uni_c2")
+    s3 = spec_from_config(c.config(), c.data_feature, c.n, 20, 3)
+    assert tuple(s3.head_begin) == (0, 24) and s3.n_ts == 4 and s3.k_total == 5   # out=3 < 6: closeness only
+    c12 = Case("tiny_multi_uni_out12")
+    s12 = spec_from_config(c12.config(), c12.data_feature, c12.n, 20, 3)
+    assert tuple(s12.head_begin) == (0, 24, 48, 72)
+    c7 = Case("tiny_multi_uni_dyn7")
+    s7 = spec_from_config(c7.config(), c7.data_feature, c7.n, 19, 3)
+    assert s7.feat_in == 7 and tuple(s7.ext_src) == (1, 2, 3, 4, 5, 6) and s7.x_feat == 7
+    cfg = dict(c.config(), adjtype="od", adpadj="none", cheb_order=3)
+    assert spec_from_config(cfg, c.data_feature, c.n, 20, 1).k_total == 3
+
+
+def test_unsupported_options_fail_loudly():
+    from multistgraph_amd import synthetic as syn
+    from multistgraph_amd.model import MultiATGCN
+    c = Case("tiny_multi_uni_c2")
+    with pytest.raises(NotImplementedError):
+        MultiATGCN(dict(c.config(), gcn_off=True), c.data_feature)
+    df = dict(c.data_feature, static=syn.make_static(c.n, 5, 0))
+    with pytest.raises(NotImplementedError):
+        MultiATGCN(c.config(), df)
+    m = MultiATGCN(c.config(), c.data_feature).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        m.predict({"X": torch.from_numpy(c.x)})      # CPU tensor: no fallback
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from multistgraph_amd import _lib
+    header = open(os.path.join(ROOT, "include", "matgcn.h")).read()
+    declared = set(re.findall(r"\b(matgcn_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    lib = _lib.load()
+    for sym in declared:
+        assert hasattr(lib, sym)
+    assert lib.matgcn_abi_version() == 1
+    assert lib.matgcn_error_string(-3) == b"configuration not supported by this build"
+
+
+def test_size_queries_and_argument_checks(lib_built):
+    from multistgraph_amd import _lib
+    from multistgraph_amd.ops import spec_from_config
+    lib = _lib.load()
+    c = Case("bm403_out24")
+    spec = spec_from_config(c.config(), c.data_feature, c.n, 20, 3)
+    d = spec.dims(64)
+    nb = C.c_size_t()
+    assert lib.matgcn_prepared_bytes(C.byref(d), C.byref(nb)) == 0
+    assert 250e6 < nb.value < 400e6       # ~300 MB of node-adaptive weights at N=403
+    assert lib.matgcn_workspace_bytes(C.byref(d), C.byref(nb)) == 0
+    assert 1e9 < nb.value < 3e9
+    lay = (C.c_int64 * 4)()
+    assert lib.matgcn_supports_layout(C.byref(d), C.byref(lay)) == 0
+    assert lay[2] == 416 and lay[3] == 4
+    d.hidden = 32
+    assert lib.matgcn_prepared_bytes(C.byref(d), C.byref(nb)) == -3     # unsupported
+    d = spec.dims(0)
+    assert lib.matgcn_prepared_bytes(C.byref(d), C.byref(nb)) == -2     # bad arg
+    assert lib.matgcn_prepared_bytes(None, C.byref(nb)) == -1           # null
