@@ -13,6 +13,7 @@
 
 // single translation unit: the kernels are compiled together with their launchers
 #include "matgcn_kernels.hip"
+#include "matgcn_node16.hip"
 
 namespace {
 
@@ -28,9 +29,10 @@ struct Plan {
   // prepared offsets (floats)
   long oSt, oPlainA, oPlainB, oPlainC;
   long oWg[MATGCN_MAX_LAYERS], oWu[MATGCN_MAX_LAYERS], oWx[MATGCN_MAX_LAYERS], oBx[MATGCN_MAX_LAYERS];
-  long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
-  long wgStride[MATGCN_MAX_LAYERS], wuStride[MATGCN_MAX_LAYERS], wxStride;
-  int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], KxL[MATGCN_MAX_LAYERS];
+  long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead, oW0x;
+  long wgStride, wuStride, wxStride;
+  int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS];
+  int nodeLds;                // dynamic LDS bytes of the node kernels
   long preparedFloats;
   // workspace offsets (floats)
   long oX0p, oX0m, oMX0, oXA0, oHx, oZHx, oG, oR, oSeq, oGX, oPX;
@@ -68,6 +70,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->Ktot = P->Ks + 1;
   P->Mp = (int)rup((long)P->Ks * P->Np, 64);
   P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 8);
+  if (P->Kx > 64) return MATGCN_ERR_UNSUPPORTED;
   P->NTc = (P->CH + 31) / 32;
   P->nc0 = P->B * P->T * P->C0;
   P->nc0p = (int)rup(P->nc0, 64);
@@ -78,13 +81,12 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->oPlainA = take(plainN); P->oPlainB = take(plainN); P->oPlainC = take(plainN);
   for (int l = 0; l < P->L; ++l) {
     P->Cl[l] = (l == 0) ? P->C0 : H;
-    P->Cpad[l] = (int)rup(P->Cl[l], 8);
-    P->KxL[l] = (l == 0) ? P->Kx : 0;
-    const long kg = P->KxL[l] + (long)P->Ktot * H;
-    P->wgStride[l] = kg * 128;
-    P->wuStride[l] = kg * 64;
-    P->oWg[l] = take((long)P->N * P->wgStride[l]);
-    P->oWu[l] = take((long)P->N * P->wuStride[l]);
+    P->Cpad[l] = (int)rup(P->Cl[l], 16);
+    P->wgStride = (long)P->Ktot * H * 128;
+    P->wuStride = (long)P->Ktot * H * 64;
+    P->oWg[l] = take((long)P->N * P->wgStride);
+    P->oWu[l] = take((long)P->N * P->wuStride);
+    if (l == 0) P->oW0x = take((long)P->N * P->Kx * 192);
     if (l > 0) {
       P->wxStride = (long)P->Ktot * H * 192;
       P->oWx[l] = take((long)P->N * P->wxStride);
@@ -108,10 +110,9 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->oR = take((long)P->N * P->B * H);
   P->seqStride = rup(rowsBT * P->Np * H, 64);
   P->oSeq = take(P->seqStride * P->L);
-  if (P->L > 1) {
-    P->oGX = take((long)P->N * rowsBT * P->Ks * H);
-    P->oPX = take((long)P->T * P->N * P->B * 192);
-  }
+  P->oPX = take((long)P->T * P->N * P->B * 192);
+  if (P->L > 1) P->oGX = take((long)P->N * rowsBT * P->Ks * H);
+  P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 4 ? P->Ks : 4)) * (int)sizeof(float);
   P->workspaceFloats = o;
   return MATGCN_OK;
 }
@@ -197,7 +198,24 @@ int layer_prepass(const Ctx& c, int l, const float* xin, int Tq) {
     hipLaunchKernelGGL(k_build_xa0, dim3(blocks_for((size_t)Tq * P.N * P.B * P.Kx)), dim3(256), 0, c.s, xin, MX0,
                        c.ws + P.oXA0, P.B, Tq, P.N, P.Np, P.C0, P.Ks, P.Kx, ld);
     CHECK_LAUNCH();
-    return MATGCN_OK;
+    // hoisted x-part of layer 0: PX[t][n][b][0:192] = XA0 . W0x[n]   (K = Kx <= 64, plain FMA kernel)
+    const dim3 g0((unsigned)P.N, (unsigned)Tq);
+    const float* xa = c.ws + P.oXA0;
+    const float* w0 = c.prep + P.oW0x;
+    float* px = c.ws + P.oPX;
+    ProfScope prof(MATGCN_PROF_PX, c.s);
+    switch (P.Kx) {
+      case 8: hipLaunchKernelGGL(k_px0<8>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 16: hipLaunchKernelGGL(k_px0<16>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 24: hipLaunchKernelGGL(k_px0<24>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 32: hipLaunchKernelGGL(k_px0<32>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 40: hipLaunchKernelGGL(k_px0<40>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 48: hipLaunchKernelGGL(k_px0<48>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 56: hipLaunchKernelGGL(k_px0<56>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      case 64: hipLaunchKernelGGL(k_px0<64>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
+      default: return MATGCN_ERR_UNSUPPORTED;
+    }
+    return launch_ok();
   }
   float* GX = c.ws + P.oGX;
   RETURN_IF(mix_rows(P, St, xin, rows, GX, c.s));
@@ -214,62 +232,81 @@ int layer_prepass(const Ctx& c, int l, const float* xin, int Tq) {
   return launch_ok();
 }
 
-// One ATGRU step of layer l at step t (of Tq): Hx <- cell(x_t, Hx); optional residual cell + blend.
-// raw: optional (B,N,128) dump of the gate pre-activation.
-int cell_step(const Ctx& c, int l, int t, int Tq, float* raw, bool gateOnly) {
+// dynamic LDS above 64 KB must be opted into once per kernel
+int node_kernels_ready(int ldsBytes) {
+  static int ready = 0;
+  if (ready >= ldsBytes) return MATGCN_OK;
+  const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), at, ldsBytes) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0>), at, ldsBytes) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), at, ldsBytes) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2>), at, ldsBytes) != hipSuccess)
+    return MATGCN_ERR_LAUNCH;
+  ready = ldsBytes;
+  return MATGCN_OK;
+}
+
+// residual-cell operands of layer l for the fused update kernel
+void fill_res_args(const Ctx& c, int l, const float* xt, long xRowStride, const float* blend, float* seq_t,
+                   long seqRowStride, Node16Args* a) {
   const Plan& P = c.P;
+  a->xt = xt; a->xRowStride = xRowStride; a->C = P.Cl[l]; a->Cpad = P.Cpad[l];
+  a->rg = c.prep + P.oRg[l]; a->rgb = c.prm->res_gate[l].bias;
+  a->ru = c.prep + P.oRu[l]; a->rub = c.prm->res_update[l].bias;
+  a->blend = blend; a->seq = seq_t; a->seqRowStride = seqRowStride;
+}
+
+// One recurrent step of layer l at step t (of Tq) on the state Hx:
+//   mix(h) -> gate -> mix(z*h) -> update [+ residual GRU cell + blend when `res` is set]   (MultiATGCN.py:120-128,
+//   142-150, 205-208).  raw: optional (B,N,128) dump of the gate pre-activation; gateOnly stops after the gate.
+int cell_step(const Ctx& c, int l, int t, int Tq, float* raw, bool gateOnly, const Node16Args* res) {
+  const Plan& P = c.P;
+  RETURN_IF(node_kernels_ready(P.nodeLds));
   const float* St = c.prep + P.oSt;
   float* Hx = c.ws + P.oHx;
   float* ZHx = c.ws + P.oZHx;
   float* G = c.ws + P.oG;
   float* R = c.ws + P.oR;
   RETURN_IF(mix_rows(P, St, Hx, P.B, G, c.s));
-  NodeArgs a;
+  Node16Args a;
   memset(&a, 0, sizeof(a));
-  if (l == 0) {
-    a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx;
-    a.xaNodeStride = (long)P.B * P.Kx; a.xaRowStride = P.Kx; a.xaLen = P.Kx;
-  } else {
-    a.px = c.ws + P.oPX + (size_t)t * P.N * P.B * 192;
-  }
-  a.ident = Hx; a.identRowStride = (long)P.Np * H;
-  a.g = G; a.Ks = P.Ks;
-  a.w = c.prep + P.oWg[l]; a.wNodeStride = P.wgStride[l];
-  a.rows = P.B; a.N = P.N; a.Np = P.Np; a.T = Tq;
-  a.raw = raw; a.zh = ZHx; a.r = R;
-  const dim3 grid(P.N, (unsigned)((P.B + 63) / 64));
+  a.s = Hx; a.g = G; a.w = c.prep + P.oWg[l];
+  a.px = c.ws + P.oPX + (size_t)t * P.N * P.B * 192;
+  a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
+  a.zh = ZHx; a.r = R; a.raw = raw;
+  const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
   {
     ProfScope prof(MATGCN_PROF_GATE, c.s);
-    hipLaunchKernelGGL(k_gate, grid, dim3(256), 0, c.s, a);
+    hipLaunchKernelGGL(k_gate16, grid, dim3(512), P.nodeLds, c.s, a);
   }
   CHECK_LAUNCH();
   if (gateOnly) return MATGCN_OK;
   RETURN_IF(mix_rows(P, St, ZHx, P.B, G, c.s));
-  a.ident = ZHx;
-  a.w = c.prep + P.oWu[l]; a.wNodeStride = P.wuStride[l];
-  a.raw = nullptr; a.zh = nullptr; a.hstate = Hx;
-  {
-    ProfScope prof(MATGCN_PROF_UPDATE, c.s);
-    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, c.s, a);
+  a.s = ZHx; a.w = c.prep + P.oWu[l]; a.raw = nullptr; a.zh = nullptr;
+  a.h = Hx; a.hout = Hx;
+  ProfScope prof(MATGCN_PROF_UPDATE, c.s);
+  if (res) {
+    a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
+    a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
+    a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
+    hipLaunchKernelGGL(k_update16<1>, grid, dim3(512), P.nodeLds, c.s, a);
+  } else {
+    hipLaunchKernelGGL(k_update16<0>, grid, dim3(512), P.nodeLds, c.s, a);
   }
   return launch_ok();
 }
 
-// residual GRU cell of layer l on (x_t, Hx) -> Hx (+ Seq_l[:, t]); blend == null gives the plain cell output
-int res_step(const Ctx& c, int l, const float* xt, long xRowStride, const float* blend, float* seq_t,
-             long seqRowStride) {
+// residual GRU cell alone (unit entry point): Hx <- cell(x_t, Hx)
+int res_step(const Ctx& c, int l, const float* xt, long xRowStride) {
   const Plan& P = c.P;
-  ResArgs a;
+  RETURN_IF(node_kernels_ready(P.nodeLds));
+  Node16Args a;
   memset(&a, 0, sizeof(a));
-  a.x = xt; a.xRowStride = xRowStride; a.C = P.Cl[l]; a.Cpad = P.Cpad[l];
-  a.h = c.ws + P.oHx; a.hout = c.ws + P.oHx;
-  a.seq = seq_t; a.seqRowStride = seqRowStride;
-  a.wg = c.prep + P.oRg[l]; a.bg = c.prm->res_gate[l].bias;
-  a.wu = c.prep + P.oRu[l]; a.bu = c.prm->res_update[l].bias;
-  a.blend = blend;
-  a.B = P.B; a.N = P.N; a.Np = P.Np;
+  a.s = c.ws + P.oHx; a.hout = c.ws + P.oHx;
+  a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
+  fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, 0, &a);
   ProfScope prof(MATGCN_PROF_RES, c.s);
-  hipLaunchKernelGGL(k_res_gru, dim3(P.N, (unsigned)((P.B + 63) / 64)), dim3(256), 0, c.s, a);
+  hipLaunchKernelGGL(k_update16<2>, dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, c.s, a);
   return launch_ok();
 }
 
@@ -299,9 +336,10 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
     CHECK_LAUNCH();
     const long xStep = (long)P.Np * P.Cl[l];
     for (int t = 0; t < P.T; ++t) {
-      RETURN_IF(cell_step(c, l, t, P.T, nullptr, false));
-      RETURN_IF(res_step(c, l, xin + t * xStep, (long)P.T * xStep, c.prm->weights_gru + (size_t)l * P.T + t,
-                         seq + (size_t)t * P.Np * H, (long)P.T * P.Np * H));
+      Node16Args res;
+      fill_res_args(c, l, xin + t * xStep, (long)P.T * xStep, c.prm->weights_gru + (size_t)l * P.T + t,
+                    seq + (size_t)t * P.Np * H, (long)P.T * P.Np * H, &res);
+      RETURN_IF(cell_step(c, l, t, P.T, nullptr, false, &res));
     }
     if (finalsUser) {
       hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, Hx,
@@ -464,25 +502,29 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     for (int part = 0; part < 2; ++part) {  // 0 gate (O=128), 1 update (O=64)
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
-      PrepAgcn a;
-      memset(&a, 0, sizeof(a));
-      a.E = params->node_emb; a.wpool = ap.weights_pool; a.bpool = ap.bias_pool;
-      a.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-      a.d = P.d; a.Ktot = P.Ktot; a.I = I; a.O = O; a.OTsrc = O / 32;
-      // recurrent (h) part of the step stream
-      a.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
-      a.nodeStride = part == 0 ? P.wgStride[l] : P.wuStride[l];
-      a.OTdst = O / 32; a.otOfs = 0;
-      if (l == 0) {
-        a.mode = 1; a.Cw = P.C0; a.iOfs = 0; a.rows = P.Kx; a.streamOfs = 0;
-        hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
+      {  // recurrent (h) rows, 16x16x4 fragment order
+        Prep16 q;
+        q.E = params->node_emb; q.wpool = ap.weights_pool; q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
+        q.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
+        q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.iOfs = P.Cl[l]; q.nG = 4 * P.Ktot;
+        hipLaunchKernelGGL(k_prep_agcn16, dim3(blocks_for((size_t)q.nG * (O / 16) * 64), N), dim3(256), 0, c.s, q);
         CHECK_LAUNCH();
       }
-      a.mode = 0; a.Cw = H; a.iOfs = P.Cl[l]; a.rows = P.Ktot * H; a.streamOfs = (long)P.KxL[l] * O;
-      hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
-      CHECK_LAUNCH();
-      if (l > 0) {
-        // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row
+      if (l == 0) {  // folded x rows + bias row of the layer-0 pre-pass
+        PrepX0 q;
+        q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
+        q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
+        q.out = prep + P.oW0x; q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.C0 = P.C0; q.Kx = P.Kx;
+        q.colOfs = part == 0 ? 0 : 128;
+        hipLaunchKernelGGL(k_prep_x0, dim3(blocks_for((size_t)P.Kx * O), N), dim3(256), 0, c.s, q);
+        CHECK_LAUNCH();
+      } else {
+        // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
+        PrepAgcn a;
+        memset(&a, 0, sizeof(a));
+        a.E = params->node_emb; a.wpool = ap.weights_pool; a.bpool = ap.bias_pool;
+        a.wg = dims->scale_by_g ? ap.weights_g : nullptr;
+        a.d = P.d; a.Ktot = P.Ktot; a.I = I; a.O = O; a.OTsrc = O / 32;
         a.out = prep + P.oWx[l]; a.nodeStride = P.wxStride; a.OTdst = 6; a.otOfs = part == 0 ? 0 : 4;
         a.mode = 0; a.Cw = H; a.iOfs = 0; a.rows = P.Ktot * H; a.streamOfs = 0;
         hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
@@ -492,12 +534,12 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
         CHECK_LAUNCH();
       }
     }
-    const int rowsR = P.Cpad[l] + H;
-    hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(rowsR / 8) * 4 * 64)), dim3(256), 0, c.s,
-                       params->res_gate[l].weight, I, 128, P.Cl[l], P.Cpad[l], rowsR, 4, prep + P.oRg[l]);
+    const int nG1 = (P.Cpad[l] + H) / 16;
+    hipLaunchKernelGGL(k_prep_linear16, dim3(blocks_for((size_t)nG1 * 8 * 64)), dim3(256), 0, c.s,
+                       params->res_gate[l].weight, I, 128, P.Cl[l], P.Cpad[l], nG1, prep + P.oRg[l]);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(rowsR / 8) * 2 * 64)), dim3(256), 0, c.s,
-                       params->res_update[l].weight, I, 64, P.Cl[l], P.Cpad[l], rowsR, 2, prep + P.oRu[l]);
+    hipLaunchKernelGGL(k_prep_linear16, dim3(blocks_for((size_t)nG1 * 4 * 64)), dim3(256), 0, c.s,
+                       params->res_update[l].weight, I, 64, P.Cl[l], P.Cpad[l], nG1, prep + P.oRu[l]);
     CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.T * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
@@ -561,7 +603,7 @@ int matgcn_agcn_gate_fwd(const matgcn_dims* dims, const matgcn_params* params, c
   float* xin;
   RETURN_IF(stage_single_step(c, layer, x, h, &xin));
   RETURN_IF(layer_prepass(c, layer, xin, 1));
-  return cell_step(c, layer, 0, 1, y, true);
+  return cell_step(c, layer, 0, 1, y, true, nullptr);
 }
 
 int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
@@ -574,7 +616,7 @@ int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, 
   float* xin;
   RETURN_IF(stage_single_step(c, layer, x, h, &xin));
   RETURN_IF(layer_prepass(c, layer, xin, 1));
-  RETURN_IF(cell_step(c, layer, 0, 1, nullptr, false));
+  RETURN_IF(cell_step(c, layer, 0, 1, nullptr, false, nullptr));
   hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
                      P.B, P.N, P.Np, H);
   return launch_ok();
@@ -589,7 +631,7 @@ int matgcn_res_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, co
   const Plan& P = c.P;
   float* xin;
   RETURN_IF(stage_single_step(c, layer, x, h, &xin));
-  RETURN_IF(res_step(c, layer, xin, (long)P.Np * P.Cl[layer], nullptr, nullptr, 0));
+  RETURN_IF(res_step(c, layer, xin, (long)P.Np * P.Cl[layer]));
   hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
                      P.B, P.N, P.Np, H);
   return launch_ok();

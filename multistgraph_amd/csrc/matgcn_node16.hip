@@ -1,0 +1,521 @@
+// matgcn_node16.hip - node-wise contraction kernels of the recurrent step (included by matgcn_capi.hip).
+//
+// One workgroup (8 waves) per node n.  For that node the step needs
+//     Y[b][o] = sum_kk A[b][kk] * W_n[kk][o],   A[b] = [ s[b][n][0:64] | G[n][b][0:Ks][0:64] ]
+// (s = h for the gate AGCN, z*h for the update AGCN; G = graph-mixed s; MultiATGCN.py:106-108 restricted to the
+// recurrent rows - the x rows live in the hoisted pre-activation PX).  All 64 batch rows of the node sit in LDS
+// (80 KB at Ks = 4, so two workgroups share a CU and one's staging hides under the other's MFMAs); the
+// node-adaptive weights - the one big stream, 172 KB per node and step - go straight from L2/Infinity Cache into
+// each wave's registers in v_mfma_f32_16x16x4_f32 B-fragment order, four k-groups ahead, and are read exactly
+// once per workgroup.
+//
+// MFMA 16x16x4 f32 operand maps: A lane l -> A[row = l&15][k = l>>4], B lane l -> B[k = l>>4][col = l&15],
+// C/D lane l, reg e -> C[row = 4*(l>>4) + e][col = l&15].  A k-group is 16 reduction indices; MFMA step s of a
+// group uses k = 16g + 4*(l>>4) + s, so both fragments of a group are one aligned float4 per lane.
+//
+// LDS tile layout: rows of 16-byte slots; slot q of row r is stored at position q ^ (r & 15) inside its
+// 16-slot block, which makes the ds_read_b128 of lane (row, kq) conflict-free without padding.
+#ifndef MATGCN_NODE16_HIP
+#define MATGCN_NODE16_HIP
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define N16_RING 10   // k-groups of weights in flight per wave (10 KB): covers an Infinity-Cache round trip
+
+struct Node16Args {
+  const float* s;        // [rows][Np][64]: h (gate / res-only) or z*h (update)
+  const float* g;        // [N][rows][Ks][64] graph-mixed s
+  const float* w;        // [N][nG][OT][64][4] recurrent rows of the node-adaptive weights (fragment order)
+  const float* px;       // [N][rows][192] hoisted pre-activation of this step (x rows + bias): gate 0:128, update 128:192
+  int rows, N, Np, Ks;
+  // gate
+  float* zh;             // out [rows][Np][64]  z*h
+  float* r;              // gate: out / update: in  [N][rows][64]
+  float* raw;            // optional (rows, N, 128) pre-activation dump (unit entry point)
+  // update
+  const float* h;        // [rows][Np][64] previous state (blend input)
+  float* hout;           // [rows][Np][64] new state (may alias h)
+  // residual GRU cell + blend (MultiATGCN.py:142-150, 205-208)
+  const float* xt;       // x_t rows: xt[b*xRowStride + n*C + c]
+  long xRowStride;
+  int C, Cpad;           // input channels of the layer, padded to 16
+  const float* rg;       // [K1/16][8][64][4] fragment-ordered res gate weight, rows [x (Cpad) | h' (64)]
+  const float* rgb;      // (128)
+  const float* ru;       // [K1/16][4][64][4]
+  const float* rub;      // (64)
+  const float* blend;    // &weights_gru[l][t] or null
+  float* seq;            // Seq_l[:, t] or null: seq[b*seqRowStride + n*64 + o]
+  long seqRowStride;
+};
+
+__device__ __forceinline__ float sigmoid16(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// keep v where ok, else zeros - element-wise, so the float4 stays in registers (a ?: on the structs would
+// select between their addresses and push them to scratch)
+__device__ __forceinline__ float4 keep4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// position (in floats) of element (row, col) of a swizzled [.][16*blocks slots] tile with `spr` slots per row
+__device__ __forceinline__ int swz(int row, int col, int spr) {
+  const int slot = col >> 2;
+  return (row * spr + ((slot & ~15) | ((slot ^ row) & 15))) * 4 + (col & 3);
+}
+
+// stage the 64-row A tile of node n: Hs <- s rows (16 slots), Gs <- G rows (16*Ks slots); rows >= a.rows are zero.
+// All loads of a round are issued before the first LDS write and none sits behind a branch (a predicated load
+// would make the compiler wait for each one separately): out-of-range rows are clamped and zeroed by a select.
+__device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int rowBase, float* Hs, float* Gs) {
+  const int tid = threadIdx.x;
+  const int row = tid >> 4, q = tid & 15;          // 32 rows x 16 slots per sweep
+  const int rA = row, rB = row + 32;
+  const bool vA = rowBase + rA < a.rows, vB = rowBase + rB < a.rows;
+  const int gA = min(rowBase + rA, a.rows - 1), gB = min(rowBase + rB, a.rows - 1);
+  float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)gA * a.Np + n) * 64 + q * 4);
+  float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)gB * a.Np + n) * 64 + q * 4);
+  const int spr = 16 * a.Ks;
+  const float4* gsrc = reinterpret_cast<const float4*>(a.g + (size_t)n * a.rows * spr * 4);
+  const int pA = q ^ (rA & 15), pB = q ^ (rB & 15);
+  for (int k0 = 0; k0 < a.Ks; k0 += 4) {
+    float4 vAk[4], vBk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = min(k0 + kk, a.Ks - 1);
+      vAk[kk] = gsrc[(size_t)gA * spr + k * 16 + q];
+      vBk[kk] = gsrc[(size_t)gB * spr + k * 16 + q];
+    }
+    if (k0 == 0) {
+      *reinterpret_cast<float4*>(&Hs[(rA * 16 + pA) * 4]) = keep4(vA, hA);
+      *reinterpret_cast<float4*>(&Hs[(rB * 16 + pB) * 4]) = keep4(vB, hB);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (k0 + kk < a.Ks) {
+        *reinterpret_cast<float4*>(&Gs[(rA * spr + (k0 + kk) * 16 + pA) * 4]) = keep4(vA, vAk[kk]);
+        *reinterpret_cast<float4*>(&Gs[(rB * spr + (k0 + kk) * 16 + pB) * 4]) = keep4(vB, vBk[kk]);
+      }
+    }
+  }
+}
+
+// A fragment of row tile rt for k-group g (g < 4: the s slots, else the mixed slots)
+__device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int Ks, int rt, int g, int i, int kq) {
+  const int row = rt * 16 + i;
+  if (g < 4) return *reinterpret_cast<const float4*>(&Hs[(row * 16 + ((4 * g + kq) ^ i)) * 4]);
+  const int q = 4 * (g - 4) + kq;
+  return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
+}
+
+// ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
+__global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Hs = lds;               // [64][16 slots]
+  float* Gs = lds + 64 * 64;     // [64][16*Ks slots]
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int nG = 4 * (1 + a.Ks);
+  // weight stream of this wave: column tile w (of 8)
+  const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * nG * 8 + w) * 64 + lane;
+  stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
+  float4 wr[N16_RING];
+#pragma unroll
+  for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)min(r, nG - 1) * 8 * 64];
+  // accumulators start from the hoisted pre-activation (x rows + bias), fetched while the tile lands
+  const int o = 16 * w + j;
+  f32x4 acc[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
+      acc[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + o];
+    }
+  __syncthreads();
+  for (int g0 = 0; g0 < nG; g0 += N16_RING) {
+#pragma unroll
+    for (int r = 0; r < N16_RING; ++r) {
+      const int g = g0 + r;
+      const float4 wv = wr[r];
+#ifndef N16_LAB_NOLOAD
+      wr[r] = wp[(size_t)min(g + N16_RING, nG - 1) * 8 * 64];
+#endif
+#ifdef N16_LAB_NOMFMA
+      if (g < nG) { acc[0][0] += wv.x + wv.y + wv.z + wv.w; }
+      if (false) {
+#else
+      if (g < nG) {
+#endif
+        float4 av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, a.Ks, rt, g, j, kq);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
+      if (b >= a.rows) continue;
+      const float v = acc[rt][e];
+      if (a.raw) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
+      const float sg = sigmoid16(v);
+      if (w < 4) a.zh[((size_t)b * a.Np + n) * 64 + o] = sg * Hs[swz(lb, o, 16)];
+      else a.r[((size_t)n * a.rows + b) * 64 + (o - 64)] = sg;
+    }
+  }
+}
+
+// ---- update AGCN + tanh + GRU blend, fused with the residual GRU cell and the per-step blend ------------------
+// MODE 0: ATGRU update only (h' out); 1: update + residual cell (+ blend); 2: residual cell only on s (unit entry)
+//
+// Waves: (ct = w&3, kh = w>>2).  The update GEMM (O = 64: 4 column tiles) splits K in two halves over the wave
+// pairs so that every weight fragment is still fetched exactly once; the halves meet in LDS.  The residual cell
+// then runs two small GEMMs on tiles that never leave LDS.  Every global operand of a later phase is requested
+// before the barrier of the phase in front of it, so its latency hides under that phase.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Hs = lds;               // [64][16 slots]: z*h during the update GEMM, then h'
+  float* Gs = lds + 64 * 64;     // [64][16*Ks slots]; reused afterwards (>= 64 KB is allocated):
+  float* Red = Gs;               //   [4 ct][4 rt][64 lanes][4]  K-half partial sums          16 KB
+  float* ZH2 = Gs + 4096;        //   [64][16 slots] z2*h'                                      16 KB
+  float* R2 = Gs + 2 * 4096;     //   [64][16 slots] r2                                         16 KB
+  float* XT = Gs + 3 * 4096;     //   [64][16 slots] x_t (zero padded)                          16 KB
+  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int ct = w & 3, kh = w >> 2;
+  const int srow = tid >> 4, sq = tid & 15;   // staging coordinates: 32 rows x 16 slots per sweep
+
+  f32x4 acc[4];
+  if (MODE != 2) {
+    const int nG = 4 * (1 + a.Ks), nGh = nG >> 1;   // nG is even: each K half is nGh groups
+    const int gBeg = kh * nGh;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * nG * 4 + ct) * 64 + lane;
+    stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
+    float4 wr[N16_RING];
+#pragma unroll
+    for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)(gBeg + min(r, nGh - 1)) * 4 * 64];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int g0 = 0; g0 < nGh; g0 += N16_RING) {
+#pragma unroll
+      for (int r = 0; r < N16_RING; ++r) {
+        const int gl = g0 + r;
+        const float4 wv = wr[r];
+        wr[r] = wp[(size_t)(gBeg + min(gl + N16_RING, nGh - 1)) * 4 * 64];
+        if (gl < nGh) {
+          const int g = gBeg + gl;
+          float4 av[4];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, a.Ks, rt, g, j, kq);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+        }
+      }
+    }
+  }
+
+  // ---- operands of the next phases, requested now ----
+  const int o4 = 16 * ct + j;                      // column of this lane in a 64-wide tile
+  float pxv[4][4], rv[4][4], hv[4][4];             // blend operands (kh == 0 waves use them)
+  if (MODE != 2) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
+        pxv[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + 128 + o4];
+        rv[rt][e] = a.r[((size_t)n * a.rows + b) * 64 + o4];
+        hv[rt][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
+      }
+  }
+  const int ngx = a.Cpad >> 4;                     // x groups of the residual GEMMs (1 or 4)
+  const int nG1 = ngx + 4;                         // <= 8
+  float4 xv[2];
+  float xs[2][4];
+  if (MODE != 0) {
+    if (a.C == 64) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        xv[it] = *reinterpret_cast<const float4*>(a.xt + (size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.xRowStride +
+                                                  (size_t)n * 64 + sq * 4);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = min(sq * 4 + cc, a.C - 1);
+          xs[it][cc] = a.xt[(size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.xRowStride + (size_t)n * a.C + c];
+        }
+    }
+  }
+
+  if (MODE != 2) {
+    __syncthreads();   // every wave is done with the mixed slots: Gs becomes scratch
+    if (kh == 1) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        *reinterpret_cast<f32x4*>(&Red[((ct * 4 + rt) * 64 + lane) * 4]) = acc[rt];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&Red[((ct * 4 + rt) * 64 + lane) * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
+          const float hc = tanhf(acc[rt][e] + p[e] + pxv[rt][e]);
+          const float rr = rv[rt][e];
+          float hn = rr * hv[rt][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
+          if (b >= a.rows) hn = 0.f;
+          if (MODE == 0) { if (b < a.rows) a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn; }
+          else Hs[swz(lb, o4, 16)] = hn;                  // h' tile for the residual cell (z*h no longer needed)
+        }
+      }
+    }
+    if (MODE == 0) return;
+  } else {
+    // residual cell only: h' := s rows
+    float4 sv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      sv[it] = *reinterpret_cast<const float4*>(a.s + ((size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.Np + n) * 64 + sq * 4);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rr = srow + 32 * it;
+      *reinterpret_cast<float4*>(&Hs[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(rowBase + rr < a.rows, sv[it]);
+    }
+  }
+
+  // ---- residual GRU cell on [x_t | h'] (MultiATGCN.py:142-150) ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {   // x_t tile (zero padded to Cpad)
+    const int rr = srow + 32 * it;
+    const bool ok = rowBase + rr < a.rows;
+    if (a.C == 64) {
+      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(ok, xv[it]);
+    } else if (sq < (a.Cpad >> 2)) {
+      float e4[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) e4[cc] = (ok && sq * 4 + cc < a.C) ? xs[it][cc] : 0.f;
+      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+    }
+  }
+  // weights of both residual GEMMs (shared by all nodes, L2-resident), requested before the tile barrier
+  const int rp = kh;
+  float4 rgv[8], ruv[8];
+  {
+    const float4* rgp = reinterpret_cast<const float4*>(a.rg) + (size_t)w * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) rgv[g] = rgp[(size_t)min(g, nG1 - 1) * 8 * 64];
+    const float4* rup = reinterpret_cast<const float4*>(a.ru) + (size_t)ct * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ruv[g] = rup[(size_t)min(g, nG1 - 1) * 4 * 64];
+  }
+  const float bg = a.rgb[16 * w + j], bu = a.rub[o4];
+  const float gate = a.blend ? sigmoid16(a.blend[0]) : 0.f;   // g = sigmoid(weights_gru[l][t]) (:208)
+  __syncthreads();
+  // GEMM 1: zr2 = sigmoid([x|h'] Wg + bg): wave w = column tile w (of 8), 4 row tiles
+  f32x4 acc1[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g < nG1) {
+      const float* T = (g < ngx) ? XT : Hs;
+      const int gg = (g < ngx) ? g : g - ngx;
+      const float4 wv = rgv[g];
+      float4 av[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) av[rt] = *reinterpret_cast<const float4*>(&T[((rt * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].x, wv.x, acc1[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].y, wv.y, acc1[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].z, wv.z, acc1[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].w, wv.w, acc1[rt]);
+    }
+  }
+  {
+    const int o = 16 * w + j;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lb = rt * 16 + 4 * kq + e;
+        const float sg = sigmoid16(acc1[rt][e] + bg);
+        if (w < 4) ZH2[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
+        else R2[swz(lb, o - 64, 16)] = sg;
+      }
+  }
+  __syncthreads();
+  // GEMM 2: hc2 = tanh([x | z2*h'] Wu + bu): wave (ct, rp) -> column tile ct, row tiles 2rp, 2rp+1
+  f32x4 acc2[2];
+  acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g < nG1) {
+      const float* T = (g < ngx) ? XT : ZH2;
+      const int gg = (g < ngx) ? g : g - ngx;
+      const float4 wv = ruv[g];
+      float4 av[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        av[q] = *reinterpret_cast<const float4*>(&T[(((2 * rp + q) * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].x, wv.x, acc2[q]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].y, wv.y, acc2[q]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].z, wv.z, acc2[q]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].w, wv.w, acc2[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int lb = (2 * rp + q) * 16 + 4 * kq + e, b = rowBase + lb;
+      if (b >= a.rows) continue;
+      const float hc = tanhf(acc2[q][e] + bu);
+      const float hp = Hs[swz(lb, o4, 16)];
+      const float rr = R2[swz(lb, o4, 16)];
+      const float res = rr * hp + (1.0f - rr) * hc;
+      const float hn = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
+      a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn;
+      if (a.seq) a.seq[(size_t)b * a.seqRowStride + (size_t)n * 64 + o4] = hn;
+    }
+}
+
+// ---- parameter-only: node-adaptive recurrent weights in 16x16x4 B-fragment order ----------------------------
+// out[n][g][ct][lane][s] = g_k * sum_d E[n][d] * Wpool[d][k][C_l + i][16ct + (lane&15)],  kk = 16g + 4(lane>>4) + s,
+// k = kk / 64, i = kk % 64  (MultiATGCN.py:102-105; softmax(weights_g) folded in)
+struct Prep16 {
+  const float* E; const float* wpool; const float* wg;
+  float* out;
+  int d, Ktot, I, O, iOfs, nG;
+};
+__global__ __launch_bounds__(256) void k_prep_agcn16(Prep16 a) {
+  const int n = blockIdx.y;
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  const int OT = a.O >> 4;
+  if (unit >= a.nG * OT * 64) return;
+  const int lane = unit & 63, ct = (unit >> 6) % OT, g = (unit >> 6) / OT;
+  const int o = 16 * ct + (lane & 15);
+  const float* e = a.E + (size_t)n * a.d;
+  float gmax = -3.0e38f, gsum = 0.f;
+  if (a.wg) {
+    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
+    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
+  }
+  float v[4];
+  const size_t dstride = (size_t)a.Ktot * a.I * a.O;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kk = 16 * g + 4 * (lane >> 4) + s;
+    const int k = kk >> 6, i = a.iOfs + (kk & 63);
+    const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
+    float acc = 0.f;
+    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
+    v[s] = a.wg ? acc * (expf(a.wg[k] - gmax) / gsum) : acc;
+  }
+  *reinterpret_cast<float4*>(a.out + ((size_t)n * a.nG * OT * 64 + unit) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// nn.Linear weight (O, I) -> [g][ct][lane][4] of B[kk][o] = W[o][in(kk)]: rows kk < Cpad map to input kk (zero
+// beyond C), rows kk >= Cpad map to input C + (kk - Cpad)
+__global__ __launch_bounds__(256) void k_prep_linear16(const float* __restrict__ W, int I, int O, int C, int Cpad,
+                                                       int nG, float* __restrict__ out) {
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  const int OT = O >> 4;
+  if (unit >= nG * OT * 64) return;
+  const int lane = unit & 63, ct = (unit >> 6) % OT, g = (unit >> 6) / OT;
+  const int o = 16 * ct + (lane & 15);
+  float v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kk = 16 * g + 4 * (lane >> 4) + s;
+    int in = -1;
+    if (kk < Cpad) { if (kk < C) in = kk; } else { in = C + (kk - Cpad); }
+    v[s] = (in >= 0 && in < I) ? W[(size_t)o * I + in] : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)unit * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- layer-0 hoisted x-part (tiny: K = Ktot*C0 + 1 <= 64): PX[t][n][b][o] = sum_j XA0[t][n][b][j] * W0x[n][j][o] ----
+// W0x rows: folded x rows (k, c) with softmax(weights_g) applied, then the bias row (XA0 carries a 1.0 there).
+struct PrepX0 {
+  const float* E; const float* wpool; const float* bpool; const float* wg;
+  float* out;            // [N][Kx][192]
+  int d, Ktot, I, O, C0, Kx, colOfs;
+};
+__global__ __launch_bounds__(256) void k_prep_x0(PrepX0 a) {
+  const int n = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.Kx * a.O) return;
+  const int jrow = idx / a.O, o = idx - jrow * a.O;
+  const float* e = a.E + (size_t)n * a.d;
+  const int nx = a.Ktot * a.C0;
+  float val = 0.f;
+  if (jrow < nx) {
+    const int k = jrow / a.C0, c = jrow - k * a.C0;
+    const float* wp = a.wpool + ((size_t)k * a.I + c) * a.O + o;
+    const size_t dstride = (size_t)a.Ktot * a.I * a.O;
+    float acc = 0.f;
+    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
+    if (a.wg) {
+      float gmax = -3.0e38f, gsum = 0.f;
+      for (int kk = 0; kk < a.Ktot; ++kk) gmax = fmaxf(gmax, a.wg[kk]);
+      for (int kk = 0; kk < a.Ktot; ++kk) gsum += expf(a.wg[kk] - gmax);
+      acc *= expf(a.wg[k] - gmax) / gsum;
+    }
+    val = acc;
+  } else if (jrow == nx) {
+    float acc = 0.f;
+    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], acc);
+    val = acc;
+  }
+  a.out[((size_t)n * a.Kx + jrow) * 192 + a.colOfs + o] = val;
+}
+
+// one workgroup (192 threads) per (node, step): thread o keeps its Kx weights in registers
+template <int KX>
+__global__ __launch_bounds__(192) void k_px0(const float* __restrict__ XA0, const float* __restrict__ W0x,
+                                             float* __restrict__ PX, int B, int N) {
+  const int n = blockIdx.x, t = blockIdx.y, o = threadIdx.x;
+  float wv[KX];
+#pragma unroll
+  for (int jj = 0; jj < KX; ++jj) wv[jj] = W0x[((size_t)n * KX + jj) * 192 + o];
+  const float* xa = XA0 + ((size_t)t * N + n) * B * KX;
+  float* dst = PX + ((size_t)t * N + n) * B * 192 + o;
+  for (int b = 0; b < B; ++b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KX; ++jj) acc = fmaf(xa[b * KX + jj], wv[jj], acc);
+    dst[(size_t)b * 192] = acc;
+  }
+}
+
+#endif

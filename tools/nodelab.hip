@@ -1,0 +1,96 @@
+// nodelab.hip - timing lab for the node-wise kernels (k_gate16 / k_update16) at Baltimore shapes.
+// hipcc -O3 --offload-arch=gfx950 -I multistgraph_amd/csrc -o tools/nodelab tools/nodelab.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstring>
+#include "matgcn_node16.hip"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// pure weight-stream probes: same launch geometry as k_gate16, no LDS, no MFMA
+template <int PATTERN>
+__global__ __launch_bounds__(512) void k_stream(const float* __restrict__ w, float* __restrict__ out, int nG) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float4* wp = PATTERN == 0 ? reinterpret_cast<const float4*>(w) + ((size_t)n * nG * 8 + wv) * 64 + lane      // [g][ct] interleaved
+                                  : reinterpret_cast<const float4*>(w) + ((size_t)(n * 8 + wv) * nG) * 64 + lane;   // wave-contiguous
+  const size_t gs = PATTERN == 0 ? 8 * 64 : 64;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 r[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r[i] = wp[(size_t)i * gs];
+  for (int g0 = 0; g0 < nG; g0 += 10) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const float4 v = r[i];
+      r[i] = wp[(size_t)min(g0 + i + 10, nG - 1) * gs];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (acc.x == 123.456f) out[threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
+int main(int argc, char** argv) {
+  const int N = 403, Np = 416, Ks = 4, B = 64;
+  const int nG = 4 * (1 + Ks);
+  hipStream_t s; CK(hipStreamCreate(&s));
+  auto dalloc = [&](size_t floats, float val) { float* p; CK(hipMalloc(&p, floats * 4)); std::vector<float> h(floats, val);
+    for (size_t i = 0; i < floats; i += 97) h[i] = 0.001f * (i % 1000); CK(hipMemcpy(p, h.data(), floats * 4, hipMemcpyHostToDevice)); return p; };
+  float* S = dalloc((size_t)B * Np * 64, 0.1f);
+  float* G = dalloc((size_t)N * B * Ks * 64, 0.1f);
+  float* Wg = dalloc((size_t)N * nG * 16 * 128, 0.01f);
+  float* Wu = dalloc((size_t)N * nG * 16 * 64, 0.01f);
+  float* PX = dalloc((size_t)N * B * 192, 0.1f);
+  float* ZH = dalloc((size_t)B * Np * 64, 0.f);
+  float* R = dalloc((size_t)N * B * 64, 0.5f);
+  float* H = dalloc((size_t)B * Np * 64, 0.1f);
+  float* XT = dalloc((size_t)B * 24 * Np * 64, 0.1f);
+  float* RG = dalloc((size_t)8 * 8 * 64 * 4, 0.01f);
+  float* RU = dalloc((size_t)8 * 4 * 64 * 4, 0.01f);
+  float* BIAS = dalloc(256, 0.1f);
+  float* SEQ = dalloc((size_t)B * 24 * Np * 64, 0.f);
+  // a second weight set so consecutive launches alternate (as gate/update of two layers do)
+  float* Wg2 = dalloc((size_t)N * nG * 16 * 128, 0.01f);
+  const int lds = (64 * 64 + 64 * 64 * 4) * 4;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int nb = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gate16, 512, lds));
+  printf("occupancy query: k_gate16 %d blocks/CU at %d B LDS\n", nb, lds);
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_update16<1>, 512, lds));
+  printf("occupancy query: k_update16<1> %d blocks/CU\n", nb);
+  Node16Args a; memset(&a, 0, sizeof(a));
+  a.s = S; a.g = G; a.w = Wg; a.px = PX; a.rows = B; a.N = N; a.Np = Np; a.Ks = Ks; a.zh = ZH; a.r = R;
+  Node16Args u = a; u.w = Wu; u.h = H; u.hout = H; u.xt = XT; u.xRowStride = (long)24 * Np * 64; u.C = 64; u.Cpad = 64;
+  u.rg = RG; u.rgb = BIAS; u.ru = RU; u.rub = BIAS; u.blend = BIAS; u.seq = SEQ; u.seqRowStride = (long)24 * Np * 64;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](const char* nm, double flops, auto&& launch) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < 20; ++i) launch(i);
+      CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-36s %8.2f us/launch  %7.1f TF/s\n", nm, ms * 1e3 / 20, flops / (ms / 20 * 1e-3) / 1e12);
+    }
+  };
+  const double fg = 2.0 * B * N * 320.0 * 128, fu = 2.0 * B * N * 320.0 * 64 + 2.0 * B * N * 128.0 * 192;
+  if (argc > 1) {   // profiling mode: a few launches of one kernel
+    for (int i = 0; i < 5; ++i) {
+      if (argv[1][0] == 'g') hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a);
+      else hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u);
+    }
+    CK(hipStreamSynchronize(s));
+    return 0;
+  }
+  timeit("stream W only, gate pattern", 66e6 * 4 / 4, [&](int) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
+  timeit("stream W only, wave-contiguous", 66e6, [&](int) { hipLaunchKernelGGL(k_stream<1>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
+  timeit("stream G only (26 MB)", 26e6, [&](int) { hipLaunchKernelGGL(k_stream<1>, dim3(N), dim3(512), 0, s, G, ZH, 8); });
+  timeit("stream W alternating 2 sets", 66e6, [&](int i) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, (i & 1) ? Wg2 : Wg, ZH, nG); });
+  timeit("gate16 (same W every launch)", fg, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a); });
+  timeit("gate16 (alternating W sets)", fg, [&](int i) { Node16Args b2 = a; b2.w = (i & 1) ? Wg2 : Wg; hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, b2); });
+  timeit("update16<1> (update+res)", fu, [&](int) { hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u); });
+  timeit("update16<0> (update only)", fu, [&](int) { hipLaunchKernelGGL(k_update16<0>, dim3(N), dim3(512), lds, s, u); });
+  { Node16Args b2 = a; b2.N = 256; timeit("gate16 256 nodes only", fg * 256 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(256), dim3(512), lds, s, b2); }); }
+  { Node16Args b2 = a; timeit("gate16 128 nodes only", fg * 128 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(128), dim3(512), lds, s, b2); }); }
+  return 0;
+}
