@@ -18,25 +18,28 @@
 namespace {
 
 constexpr int H = 64;
+constexpr int MAX_STEPS = 64;     // in_steps the wavefront scheduler keeps events for
+constexpr int X_CHUNK = 4;        // steps per hoisted x-part chunk of layers >= 1
 
 inline long rup(long v, long m) { return (v + m - 1) / m * m; }
 
 // ---- derived sizes ---------------------------------------------------------------------------------
 struct Plan {
-  int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od;
+  int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od, Tc;
   int nc0, nc0p;              // layer-0 plain-matrix columns (B*T*C0) and padded to 64
   int NpC;                    // N rounded up to 64: plain N x N scratch leading dimension
   // prepared offsets (floats)
   long oSt, oPlainA, oPlainB, oPlainC;
   long oWg[MATGCN_MAX_LAYERS], oWu[MATGCN_MAX_LAYERS], oWx[MATGCN_MAX_LAYERS], oBx[MATGCN_MAX_LAYERS];
-  long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead, oW0x;
-  long wgStride, wuStride, wxStride;
-  int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS];
+  long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
+  long wxStride;
+  int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], nGx[MATGCN_MAX_LAYERS];
   int nodeLds;                // dynamic LDS bytes of the node kernels
   long preparedFloats;
-  // workspace offsets (floats)
-  long oX0p, oX0m, oMX0, oXA0, oHx, oZHx, oG, oR, oSeq, oGX, oPX;
-  long seqStride;             // floats per layer sequence
+  // workspace offsets (floats); state buffers are per layer so that layers can run concurrently
+  long oX0p, oX0m, oMX0, oXA0;
+  long oHx[MATGCN_MAX_LAYERS], oZHx[MATGCN_MAX_LAYERS], oG[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS];
+  long oSeq[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS], oPX[MATGCN_MAX_LAYERS];
   long workspaceFloats;
 };
 
@@ -45,6 +48,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   if (D->batch < 1 || D->nodes < 1 || D->layers < 1 || D->layers > MATGCN_MAX_LAYERS) return MATGCN_ERR_BAD_ARG;
   if (D->hidden != H) return MATGCN_ERR_UNSUPPORTED;
   if (D->in_steps < 1 || D->x_steps < D->in_steps || D->x_feat < 1) return MATGCN_ERR_BAD_ARG;
+  if (D->in_steps > MAX_STEPS) return MATGCN_ERR_UNSUPPORTED;
   if (D->out_dim < 1 || D->out_channels < 1 || D->out_channels % D->out_dim) return MATGCN_ERR_BAD_ARG;
   if (D->out_channels > 64) return MATGCN_ERR_UNSUPPORTED;
   if (D->feat_in < D->out_dim || D->feat_in - D->out_dim > MATGCN_MAX_EXT || D->feat_in > 64) return MATGCN_ERR_BAD_ARG;
@@ -69,9 +73,9 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->Ks = P->nFirst * (D->cheb_k - 1);
   P->Ktot = P->Ks + 1;
   P->Mp = (int)rup((long)P->Ks * P->Np, 64);
-  P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 8);
-  if (P->Kx > 64) return MATGCN_ERR_UNSUPPORTED;
+  P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 16);   // folded x rows of layer 0 (+ bias row), whole k-groups
   P->NTc = (P->CH + 31) / 32;
+  P->Tc = P->T < X_CHUNK ? P->T : X_CHUNK;
   P->nc0 = P->B * P->T * P->C0;
   P->nc0p = (int)rup(P->nc0, 64);
   long o = 0;
@@ -82,11 +86,10 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   for (int l = 0; l < P->L; ++l) {
     P->Cl[l] = (l == 0) ? P->C0 : H;
     P->Cpad[l] = (int)rup(P->Cl[l], 16);
-    P->wgStride = (long)P->Ktot * H * 128;
-    P->wuStride = (long)P->Ktot * H * 64;
-    P->oWg[l] = take((long)P->N * P->wgStride);
-    P->oWu[l] = take((long)P->N * P->wuStride);
-    if (l == 0) P->oW0x = take((long)P->N * P->Kx * 192);
+    P->nGx[l] = (l == 0) ? P->Kx / 16 : 0;
+    const long kt = (long)P->Ktot * H + 16L * P->nGx[l];
+    P->oWg[l] = take((long)P->N * kt * 128);
+    P->oWu[l] = take((long)P->N * kt * 64);
     if (l > 0) {
       P->wxStride = (long)P->Ktot * H * 192;
       P->oWx[l] = take((long)P->N * P->wxStride);
@@ -97,6 +100,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   }
   P->oHead = take((long)P->T * H * 32 * P->NTc);
   P->preparedFloats = o;
+  P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 4 ? P->Ks : 4)) * (int)sizeof(float);
   // workspace
   o = 0;
   const long rowsBT = (long)P->B * P->T;
@@ -104,15 +108,17 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->oX0m = take((long)P->Np * P->nc0p);
   P->oMX0 = take((long)P->Mp * P->nc0p);
   P->oXA0 = take((long)P->T * P->N * P->B * P->Kx);
-  P->oHx = take((long)P->B * P->Np * H);
-  P->oZHx = take((long)P->B * P->Np * H);
-  P->oG = take((long)P->N * P->B * P->Ks * H);
-  P->oR = take((long)P->N * P->B * H);
-  P->seqStride = rup(rowsBT * P->Np * H, 64);
-  P->oSeq = take(P->seqStride * P->L);
-  P->oPX = take((long)P->T * P->N * P->B * 192);
-  if (P->L > 1) P->oGX = take((long)P->N * rowsBT * P->Ks * H);
-  P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 4 ? P->Ks : 4)) * (int)sizeof(float);
+  for (int l = 0; l < P->L; ++l) {
+    P->oHx[l] = take((long)P->B * P->Np * H);
+    P->oZHx[l] = take((long)P->B * P->Np * H);
+    P->oG[l] = take((long)P->N * P->B * P->Ks * H);
+    P->oR[l] = take((long)P->N * P->B * H);
+    P->oSeq[l] = take(rowsBT * P->Np * H);
+    if (l > 0) {
+      P->oGX[l] = take((long)P->N * P->B * P->Tc * P->Ks * H);
+      P->oPX[l] = take((long)P->T * P->N * P->B * 192);
+    }
+  }
   P->workspaceFloats = o;
   return MATGCN_OK;
 }
@@ -150,8 +156,46 @@ inline int launch_ok() { return hipGetLastError() == hipSuccess ? MATGCN_OK : MA
     int rc__ = (x);             \
     if (rc__ != MATGCN_OK) return rc__; \
   } while (0)
+#define HIP_OK(x)                                      \
+  do {                                                 \
+    if ((x) != hipSuccess) return MATGCN_ERR_LAUNCH;   \
+  } while (0)
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// ---- layer wavefront: one stream per recurrent chain and per x-part pre-pass ----------------------------
+// Layer l+1 only needs step t of layer l to start its own step t (MultiATGCN.py:194-212 runs the layers one
+// after the other, but the data dependence is the diagonal), so the chains of the layers run on separate HIP
+// streams, tied together by events.  While one chain sits in a memory-bound phase (weight stream of a node
+// kernel) the other can own the matrix cores (graph mix), and the tails of one kernel fill with the other's
+// workgroups.  Streams and events are created once, on first use; no call creates or destroys them afterwards.
+struct Wavefront {
+  bool ready = false;
+  hipStream_t chain[MATGCN_MAX_LAYERS];            // [0] unused: layer 0 runs on the caller's stream
+  hipStream_t xpart[MATGCN_MAX_LAYERS];
+  hipEvent_t fork, done[MATGCN_MAX_LAYERS];
+  hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
+  hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
+};
+Wavefront g_wf;
+
+int wavefront_ready() {
+  if (g_wf.ready) return MATGCN_OK;
+  for (int l = 1; l < MATGCN_MAX_LAYERS; ++l) {
+    HIP_OK(hipStreamCreateWithFlags(&g_wf.chain[l], hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&g_wf.xpart[l], hipStreamNonBlocking));
+  }
+  HIP_OK(hipEventCreateWithFlags(&g_wf.fork, hipEventDisableTiming));
+  for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
+    HIP_OK(hipEventCreateWithFlags(&g_wf.done[l], hipEventDisableTiming));
+    for (int t = 0; t < MAX_STEPS; ++t) {
+      HIP_OK(hipEventCreateWithFlags(&g_wf.step[l][t], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_wf.xdone[l][t], hipEventDisableTiming));
+    }
+  }
+  g_wf.ready = true;
+  return MATGCN_OK;
+}
 
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
@@ -166,7 +210,7 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   return launch_ok();
 }
 
-// mix of a [rows][Np][64] buffer into the node-major gather buffer G [N][rows][Ks][64]
+// mix of `rows` contiguous [Np][64] slabs into the node-major buffer G [N][rows][Ks][64]
 int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s) {
   return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, (long)rows * P.Ks * H, H, (long)P.Ks * H, P.Ks,
                     P.Ks * P.Np, s);
@@ -181,130 +225,115 @@ struct Ctx {
   hipStream_t s;
 };
 
-// x-part of layer l for `Tq` steps: folded rows (layer 0) or hoisted PX (layers >= 1).
-// xin: [B][Tq][Np][C_l] padded rows.
-int layer_prepass(const Ctx& c, int l, const float* xin, int Tq) {
-  const Plan& P = c.P;
-  const int rows = P.B * Tq;
-  const float* St = c.prep + P.oSt;
-  if (l == 0) {
-    const int ld = (int)rup((long)rows * P.C0, 64);
-    float* X0m = c.ws + P.oX0m;
-    float* MX0 = c.ws + P.oMX0;
-    hipLaunchKernelGGL(k_x0_to_matrix, dim3(blocks_for((size_t)P.Np * ld)), dim3(256), 0, c.s, xin, X0m, rows, P.Np,
-                       P.C0, ld);
-    CHECK_LAUNCH();
-    RETURN_IF(launch_mix(P, St, X0m, 64, ld, ld / 64, MX0, (long)ld, (long)P.Np * ld, 64, P.Ks, P.Ks * P.Np, c.s));
-    hipLaunchKernelGGL(k_build_xa0, dim3(blocks_for((size_t)Tq * P.N * P.B * P.Kx)), dim3(256), 0, c.s, xin, MX0,
-                       c.ws + P.oXA0, P.B, Tq, P.N, P.Np, P.C0, P.Ks, P.Kx, ld);
-    CHECK_LAUNCH();
-    // hoisted x-part of layer 0: PX[t][n][b][0:192] = XA0 . W0x[n]   (K = Kx <= 64, plain FMA kernel)
-    const dim3 g0((unsigned)P.N, (unsigned)Tq);
-    const float* xa = c.ws + P.oXA0;
-    const float* w0 = c.prep + P.oW0x;
-    float* px = c.ws + P.oPX;
-    ProfScope prof(MATGCN_PROF_PX, c.s);
-    switch (P.Kx) {
-      case 8: hipLaunchKernelGGL(k_px0<8>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 16: hipLaunchKernelGGL(k_px0<16>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 24: hipLaunchKernelGGL(k_px0<24>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 32: hipLaunchKernelGGL(k_px0<32>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 40: hipLaunchKernelGGL(k_px0<40>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 48: hipLaunchKernelGGL(k_px0<48>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 56: hipLaunchKernelGGL(k_px0<56>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      case 64: hipLaunchKernelGGL(k_px0<64>, g0, dim3(192), 0, c.s, xa, w0, px, P.B, P.N); break;
-      default: return MATGCN_ERR_UNSUPPORTED;
-    }
-    return launch_ok();
-  }
-  float* GX = c.ws + P.oGX;
-  RETURN_IF(mix_rows(P, St, xin, rows, GX, c.s));
-  NodeArgs a;
-  memset(&a, 0, sizeof(a));
-  a.ident = xin; a.identRowStride = (long)P.Np * H;
-  a.g = GX; a.Ks = P.Ks;
-  a.w = c.prep + P.oWx[l]; a.wNodeStride = P.wxStride;
-  a.rows = rows; a.N = P.N; a.Np = P.Np; a.T = Tq;
-  a.bias = c.prep + P.oBx[l];
-  a.pxOut = c.ws + P.oPX;
-  ProfScope prof(MATGCN_PROF_PX, c.s);
-  hipLaunchKernelGGL(k_px, dim3(P.N, (unsigned)((rows + 63) / 64)), dim3(256), 0, c.s, a);
-  return launch_ok();
-}
-
 // dynamic LDS above 64 KB must be opted into once per kernel
 int node_kernels_ready(int ldsBytes) {
   static int ready = 0;
   if (ready >= ldsBytes) return MATGCN_OK;
   const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), at, ldsBytes) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0>), at, ldsBytes) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), at, ldsBytes) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2>), at, ldsBytes) != hipSuccess)
-    return MATGCN_ERR_LAUNCH;
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2>), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
 }
 
-// residual-cell operands of layer l for the fused update kernel
+// layer 0: fold the x part of all Tq steps into XA0[t][n][b][Kx] = [x | mix_k(x) | 1 | 0..]; the node kernels
+// contract it with the x rows of the layer-0 weights (k-groups nG.. of the node stream).  xin: [B][Tq][Np][C0].
+int fold_x0(const Ctx& c, const float* xin, int Tq, hipStream_t s) {
+  const Plan& P = c.P;
+  const int rows = P.B * Tq;
+  const float* St = c.prep + P.oSt;
+  const int ld = (int)rup((long)rows * P.C0, 64);
+  float* X0m = c.ws + P.oX0m;
+  float* MX0 = c.ws + P.oMX0;
+  hipLaunchKernelGGL(k_x0_to_matrix, dim3(blocks_for((size_t)P.Np * ld)), dim3(256), 0, s, xin, X0m, rows, P.Np, P.C0,
+                     ld);
+  CHECK_LAUNCH();
+  RETURN_IF(launch_mix(P, St, X0m, 64, ld, ld / 64, MX0, (long)ld, (long)P.Np * ld, 64, P.Ks, P.Ks * P.Np, s));
+  hipLaunchKernelGGL(k_build_xa0, dim3(blocks_for((size_t)Tq * P.N * P.B * P.Kx)), dim3(256), 0, s, xin, MX0,
+                     c.ws + P.oXA0, P.B, Tq, P.N, P.Np, P.C0, P.Ks, P.Kx, ld);
+  return launch_ok();
+}
+
+// layers >= 1: hoisted x part of steps [t0, t0+nt) -> PX_l[t0..].  xin: time-major rows [nt*B][Np][64] of the
+// layer below (MultiATGCN.py:106-108 restricted to the x rows, + bias)
+int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s) {
+  const Plan& P = c.P;
+  const int rows = P.B * nt;
+  float* GX = c.ws + P.oGX[l];
+  RETURN_IF(mix_rows(P, c.prep + P.oSt, xin, rows, GX, s));
+  NodeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ident = xin; a.identRowStride = (long)P.Np * H;
+  a.g = GX; a.Ks = P.Ks;
+  a.w = c.prep + P.oWx[l]; a.wNodeStride = P.wxStride;
+  a.rows = rows; a.N = P.N; a.Np = P.Np; a.B = P.B;
+  a.bias = c.prep + P.oBx[l];
+  a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.B * 192;
+  ProfScope prof(MATGCN_PROF_PX, s);
+  hipLaunchKernelGGL(k_px, dim3(P.N, (unsigned)((rows + 63) / 64)), dim3(256), 0, s, a);
+  return launch_ok();
+}
+
+// residual-cell operands of layer l at step t for the fused update kernel
 void fill_res_args(const Ctx& c, int l, const float* xt, long xRowStride, const float* blend, float* seq_t,
-                   long seqRowStride, Node16Args* a) {
+                   Node16Args* a) {
   const Plan& P = c.P;
   a->xt = xt; a->xRowStride = xRowStride; a->C = P.Cl[l]; a->Cpad = P.Cpad[l];
   a->rg = c.prep + P.oRg[l]; a->rgb = c.prm->res_gate[l].bias;
   a->ru = c.prep + P.oRu[l]; a->rub = c.prm->res_update[l].bias;
-  a->blend = blend; a->seq = seq_t; a->seqRowStride = seqRowStride;
+  a->blend = blend; a->seq = seq_t; a->seqRowStride = (long)P.Np * H;
 }
 
-// One recurrent step of layer l at step t (of Tq) on the state Hx:
+// One recurrent step of layer l at step t on the layer's state Hx_l:
 //   mix(h) -> gate -> mix(z*h) -> update [+ residual GRU cell + blend when `res` is set]   (MultiATGCN.py:120-128,
 //   142-150, 205-208).  raw: optional (B,N,128) dump of the gate pre-activation; gateOnly stops after the gate.
-int cell_step(const Ctx& c, int l, int t, int Tq, float* raw, bool gateOnly, const Node16Args* res) {
+int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node16Args* res, hipStream_t s) {
   const Plan& P = c.P;
-  RETURN_IF(node_kernels_ready(P.nodeLds));
   const float* St = c.prep + P.oSt;
-  float* Hx = c.ws + P.oHx;
-  float* ZHx = c.ws + P.oZHx;
-  float* G = c.ws + P.oG;
-  float* R = c.ws + P.oR;
-  RETURN_IF(mix_rows(P, St, Hx, P.B, G, c.s));
+  float* Hx = c.ws + P.oHx[l];
+  float* ZHx = c.ws + P.oZHx[l];
+  float* G = c.ws + P.oG[l];
+  float* R = c.ws + P.oR[l];
+  RETURN_IF(mix_rows(P, St, Hx, P.B, G, s));
   Node16Args a;
   memset(&a, 0, sizeof(a));
   a.s = Hx; a.g = G; a.w = c.prep + P.oWg[l];
-  a.px = c.ws + P.oPX + (size_t)t * P.N * P.B * 192;
+  if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
+  else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.B * 192;
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   a.zh = ZHx; a.r = R; a.raw = raw;
   const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
   {
-    ProfScope prof(MATGCN_PROF_GATE, c.s);
-    hipLaunchKernelGGL(k_gate16, grid, dim3(512), P.nodeLds, c.s, a);
+    ProfScope prof(MATGCN_PROF_GATE, s);
+    hipLaunchKernelGGL(k_gate16, grid, dim3(512), P.nodeLds, s, a);
   }
   CHECK_LAUNCH();
   if (gateOnly) return MATGCN_OK;
-  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, c.s));
+  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, s));
   a.s = ZHx; a.w = c.prep + P.oWu[l]; a.raw = nullptr; a.zh = nullptr;
   a.h = Hx; a.hout = Hx;
-  ProfScope prof(MATGCN_PROF_UPDATE, c.s);
+  ProfScope prof(MATGCN_PROF_UPDATE, s);
   if (res) {
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    hipLaunchKernelGGL(k_update16<1>, grid, dim3(512), P.nodeLds, c.s, a);
+    hipLaunchKernelGGL(k_update16<1>, grid, dim3(512), P.nodeLds, s, a);
   } else {
-    hipLaunchKernelGGL(k_update16<0>, grid, dim3(512), P.nodeLds, c.s, a);
+    hipLaunchKernelGGL(k_update16<0>, grid, dim3(512), P.nodeLds, s, a);
   }
   return launch_ok();
 }
 
-// residual GRU cell alone (unit entry point): Hx <- cell(x_t, Hx)
+// residual GRU cell alone (unit entry point): Hx_l <- cell(x_t, Hx_l)
 int res_step(const Ctx& c, int l, const float* xt, long xRowStride) {
   const Plan& P = c.P;
-  RETURN_IF(node_kernels_ready(P.nodeLds));
   Node16Args a;
   memset(&a, 0, sizeof(a));
-  a.s = c.ws + P.oHx; a.hout = c.ws + P.oHx;
+  a.s = c.ws + P.oHx[l]; a.hout = c.ws + P.oHx[l];
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
-  fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, 0, &a);
+  fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, &a);
   ProfScope prof(MATGCN_PROF_RES, c.s);
   hipLaunchKernelGGL(k_update16<2>, dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, c.s, a);
   return launch_ok();
@@ -314,39 +343,68 @@ int zero_async(float* p, long floats, hipStream_t s) {
   return hipMemsetAsync(p, 0, (size_t)floats * sizeof(float), s) == hipSuccess ? MATGCN_OK : MATGCN_ERR_LAUNCH;
 }
 
-// the encoder over padded buffers: x0p [B][T][Np][C0] -> Seq[L-1]; finalsUser (L,B,N,H) optional
+// the encoder over padded buffers: x0p [B][T][Np][C0] -> Seq_{L-1} (time-major [T][B][Np][64]); finalsUser
+// (L,B,N,H) optional.  Layers run as a wavefront over streams (see Wavefront).
 int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* finalsUser) {
   const Plan& P = c.P;
-  float* Hx = c.ws + P.oHx;
-  RETURN_IF(zero_async(c.ws + P.oZHx, (long)P.B * P.Np * H, c.s));
-  if (P.Np != P.N) {
-    for (int l = 0; l < P.L; ++l) {
-      const size_t cnt = (size_t)P.B * P.T * (P.Np - P.N) * H;
-      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for(cnt)), dim3(256), 0, c.s,
-                         c.ws + P.oSeq + l * P.seqStride, P.B * P.T, P.N, P.Np, H);
-      CHECK_LAUNCH();
+  RETURN_IF(node_kernels_ready(P.nodeLds));
+  RETURN_IF(wavefront_ready());
+  Wavefront& W = g_wf;
+  const bool multi = P.L > 1;
+  if (multi) {
+    HIP_OK(hipEventRecord(W.fork, c.s));
+    for (int l = 1; l < P.L; ++l) {
+      HIP_OK(hipStreamWaitEvent(W.chain[l], W.fork, 0));
+      HIP_OK(hipStreamWaitEvent(W.xpart[l], W.fork, 0));
     }
   }
+  RETURN_IF(fold_x0(c, x0p, P.T, c.s));
   for (int l = 0; l < P.L; ++l) {
-    const float* xin = (l == 0) ? x0p : c.ws + P.oSeq + (l - 1) * P.seqStride;
-    float* seq = c.ws + P.oSeq + l * P.seqStride;
-    RETURN_IF(layer_prepass(c, l, xin, P.T));
-    hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, c.s,
-                       h0User ? h0User + (size_t)l * P.B * P.N * H : nullptr, Hx, P.B, P.N, P.Np, H);
+    hipStream_t cs = (l == 0) ? c.s : W.chain[l];
+    RETURN_IF(zero_async(c.ws + P.oZHx[l], (long)P.B * P.Np * H, cs));
+    if (P.Np != P.N) {
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)P.B * P.T * (P.Np - P.N) * H)), dim3(256), 0, cs,
+                         c.ws + P.oSeq[l], P.B * P.T, P.N, P.Np, H);
+      CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, cs,
+                       h0User ? h0User + (size_t)l * P.B * P.N * H : nullptr, c.ws + P.oHx[l], P.B, P.N, P.Np, H);
     CHECK_LAUNCH();
-    const long xStep = (long)P.Np * P.Cl[l];
+    const float* below = (l == 0) ? nullptr : c.ws + P.oSeq[l - 1];
+    float* seq = c.ws + P.oSeq[l];
+    const long stepRows = (long)P.B * P.Np * H;     // one step of a time-major sequence
+    int nextChunk = 0;
     for (int t = 0; t < P.T; ++t) {
+      if (l > 0 && t == nextChunk) {
+        // x-part chunk [t, t+nt) of this layer, as soon as the layer below has produced those steps; the first
+        // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
+        int nt = (t < 2) ? 1 : (t < 4 ? 2 : P.Tc);
+        if (nt > P.Tc) nt = P.Tc;
+        if (t + nt > P.T) nt = P.T - t;
+        nextChunk = t + nt;
+        HIP_OK(hipStreamWaitEvent(W.xpart[l], W.step[l - 1][t + nt - 1], 0));
+        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, W.xpart[l]));
+        HIP_OK(hipEventRecord(W.xdone[l][t], W.xpart[l]));
+        HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
+      }
       Node16Args res;
-      fill_res_args(c, l, xin + t * xStep, (long)P.T * xStep, c.prm->weights_gru + (size_t)l * P.T + t,
-                    seq + (size_t)t * P.Np * H, (long)P.T * P.Np * H, &res);
-      RETURN_IF(cell_step(c, l, t, P.T, nullptr, false, &res));
+      if (l == 0)
+        fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0,
+                      c.prm->weights_gru + (size_t)l * P.T + t, seq + t * stepRows, &res);
+      else
+        fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, c.prm->weights_gru + (size_t)l * P.T + t,
+                      seq + t * stepRows, &res);
+      RETURN_IF(cell_step(c, l, t, nullptr, false, &res, cs));
+      if (l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
     }
     if (finalsUser) {
-      hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, Hx,
+      hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, cs, c.ws + P.oHx[l],
                          finalsUser + (size_t)l * P.B * P.N * H, P.B, P.N, P.Np, H);
       CHECK_LAUNCH();
     }
+    if (l > 0) HIP_OK(hipEventRecord(W.done[l], cs));
   }
+  for (int l = 1; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(c.s, W.done[l], 0));   // join
   return MATGCN_OK;
 }
 
@@ -365,6 +423,7 @@ int fuse_padded(const Ctx& c, const float* X, float* x0p) {
   return launch_ok();
 }
 
+// seqp: time-major padded sequence [T][B][Np][64]
 int head_padded(const Ctx& c, const float* seqp, float* out) {
   const Plan& P = c.P;
   HeadArgs a;
@@ -394,6 +453,29 @@ int check_layer_params(const matgcn_dims* D, const matgcn_params* p) {
     if (!p->res_gate[l].weight || !p->res_gate[l].bias || !p->res_update[l].weight || !p->res_update[l].bias)
       return MATGCN_ERR_NULL;
   }
+  return MATGCN_OK;
+}
+
+// shared by the three single-step entry points: stage x (B,N,C_l) as a one-step sequence, h as the layer's state,
+// and the x part of that step (XA0 for layer 0, PX_l[0] for deeper layers)
+int stage_single_step(const Ctx& c, int layer, const float* x, const float* h, bool xpart, float** xin_out) {
+  const Plan& P = c.P;
+  if (layer < 0 || layer >= P.L) return MATGCN_ERR_BAD_ARG;
+  RETURN_IF(node_kernels_ready(P.nodeLds));
+  // layer 0 stages into x0p, deeper layers into step 0 of the sequence of the layer below
+  float* xin = (layer == 0) ? c.ws + P.oX0p : c.ws + P.oSeq[layer - 1];
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * P.Cl[layer])), dim3(256), 0, c.s, x, xin, P.B,
+                     P.N, P.Np, P.Cl[layer]);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, c.s, h, c.ws + P.oHx[layer],
+                     P.B, P.N, P.Np, H);
+  CHECK_LAUNCH();
+  RETURN_IF(zero_async(c.ws + P.oZHx[layer], (long)P.B * P.Np * H, c.s));
+  if (xpart) {
+    if (layer == 0) RETURN_IF(fold_x0(c, xin, 1, c.s));
+    else RETURN_IF(hoist_x(c, layer, xin, 0, 1, c.s));
+  }
+  *xin_out = xin;
   return MATGCN_OK;
 }
 
@@ -502,21 +584,22 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     for (int part = 0; part < 2; ++part) {  // 0 gate (O=128), 1 update (O=64)
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
+      float* stream = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
       {  // recurrent (h) rows, 16x16x4 fragment order
         Prep16 q;
         q.E = params->node_emb; q.wpool = ap.weights_pool; q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-        q.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
-        q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.iOfs = P.Cl[l]; q.nG = 4 * P.Ktot;
+        q.out = stream;
+        q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.iOfs = P.Cl[l]; q.nG = 4 * P.Ktot; q.nGx = P.nGx[l];
         hipLaunchKernelGGL(k_prep_agcn16, dim3(blocks_for((size_t)q.nG * (O / 16) * 64), N), dim3(256), 0, c.s, q);
         CHECK_LAUNCH();
       }
-      if (l == 0) {  // folded x rows + bias row of the layer-0 pre-pass
-        PrepX0 q;
+      if (l == 0) {  // folded x rows + bias row, appended to the node stream
+        PrepX16 q;
         q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
         q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-        q.out = prep + P.oW0x; q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.C0 = P.C0; q.Kx = P.Kx;
-        q.colOfs = part == 0 ? 0 : 128;
-        hipLaunchKernelGGL(k_prep_x0, dim3(blocks_for((size_t)P.Kx * O), N), dim3(256), 0, c.s, q);
+        q.out = stream; q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.C0 = P.C0;
+        q.nG = 4 * P.Ktot; q.nGx = P.nGx[0];
+        hipLaunchKernelGGL(k_prep_x16, dim3(blocks_for((size_t)q.nGx * (O / 16) * 64), N), dim3(256), 0, c.s, q);
         CHECK_LAUNCH();
       } else {
         // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
@@ -559,7 +642,7 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
-  return head_padded(c, c.ws + P.oSeq + (P.L - 1) * P.seqStride, out);
+  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
 }
 
 int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, const float* X, float* x0,
@@ -577,23 +660,6 @@ int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, cons
   return launch_ok();
 }
 
-// shared by the three single-step entry points: stage x (B,N,C_l) as a one-step sequence and h as the state
-static int stage_single_step(const Ctx& c, int layer, const float* x, const float* h, float** xin_out) {
-  const Plan& P = c.P;
-  if (layer < 0 || layer >= P.L) return MATGCN_ERR_BAD_ARG;
-  // layer 0 stages into x0p, deeper layers into the (unused) first sequence buffer
-  float* xin = (layer == 0) ? c.ws + P.oX0p : c.ws + P.oSeq;
-  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * P.Cl[layer])), dim3(256), 0, c.s, x, xin, P.B,
-                     P.N, P.Np, P.Cl[layer]);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, c.s, h, c.ws + P.oHx, P.B,
-                     P.N, P.Np, H);
-  CHECK_LAUNCH();
-  RETURN_IF(zero_async(c.ws + P.oZHx, (long)P.B * P.Np * H, c.s));
-  *xin_out = xin;
-  return MATGCN_OK;
-}
-
 int matgcn_agcn_gate_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
                          const float* x, const float* h, float* y, void* workspace, size_t workspace_bytes,
                          void* stream) {
@@ -601,9 +667,8 @@ int matgcn_agcn_gate_fwd(const matgcn_dims* dims, const matgcn_params* params, c
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   float* xin;
-  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
-  RETURN_IF(layer_prepass(c, layer, xin, 1));
-  return cell_step(c, layer, 0, 1, y, true, nullptr);
+  RETURN_IF(stage_single_step(c, layer, x, h, true, &xin));
+  return cell_step(c, layer, 0, y, true, nullptr, c.s);
 }
 
 int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, int layer,
@@ -614,11 +679,10 @@ int matgcn_atgru_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, 
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   const Plan& P = c.P;
   float* xin;
-  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
-  RETURN_IF(layer_prepass(c, layer, xin, 1));
-  RETURN_IF(cell_step(c, layer, 0, 1, nullptr, false, nullptr));
-  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
-                     P.B, P.N, P.Np, H);
+  RETURN_IF(stage_single_step(c, layer, x, h, true, &xin));
+  RETURN_IF(cell_step(c, layer, 0, nullptr, false, nullptr, c.s));
+  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx[layer],
+                     h_out, P.B, P.N, P.Np, H);
   return launch_ok();
 }
 
@@ -630,10 +694,10 @@ int matgcn_res_cell_fwd(const matgcn_dims* dims, const matgcn_params* params, co
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   const Plan& P = c.P;
   float* xin;
-  RETURN_IF(stage_single_step(c, layer, x, h, &xin));
+  RETURN_IF(stage_single_step(c, layer, x, h, false, &xin));
   RETURN_IF(res_step(c, layer, xin, (long)P.Np * P.Cl[layer]));
-  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx, h_out,
-                     P.B, P.N, P.Np, H);
+  hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, c.s, c.ws + P.oHx[layer],
+                     h_out, P.B, P.N, P.Np, H);
   return launch_ok();
 }
 
@@ -651,8 +715,8 @@ int matgcn_encoder_fwd(const matgcn_dims* dims, const matgcn_params* params, con
   CHECK_LAUNCH();
   RETURN_IF(encoder_padded(c, x0p, h0, finals));
   if (seq) {
-    hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.T * P.N * H)), dim3(256), 0, c.s,
-                       c.ws + P.oSeq + (P.L - 1) * P.seqStride, seq, P.B * P.T, P.N, P.Np, H);
+    hipLaunchKernelGGL(k_unpack_seq_tm, dim3(blocks_for((size_t)P.B * P.T * P.N * H)), dim3(256), 0, c.s,
+                       c.ws + P.oSeq[P.L - 1], seq, P.B, P.T, P.N, P.Np, H);
     CHECK_LAUNCH();
   }
   return MATGCN_OK;
@@ -665,9 +729,9 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   if (!params->end_conv_bias) return MATGCN_ERR_NULL;
   const Plan& P = c.P;
-  float* seqp = c.ws + P.oSeq + (P.L - 1) * P.seqStride;
-  hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.T * P.Np * H)), dim3(256), 0, c.s, seq, seqp,
-                     P.B * P.T, P.N, P.Np, H);
+  float* seqp = c.ws + P.oSeq[P.L - 1];
+  hipLaunchKernelGGL(k_pack_seq_tm, dim3(blocks_for((size_t)P.B * P.T * P.Np * H)), dim3(256), 0, c.s, seq, seqp,
+                     P.B, P.T, P.N, P.Np, H);
   CHECK_LAUNCH();
   return head_padded(c, seqp, out);
 }

@@ -42,41 +42,20 @@ struct MixArgs {
   int Np, N, Ks, nK, nColTiles, nRowTiles;
 };
 
-struct NodeArgs {
-  const float* xa;       // folded x-part rows (layer 0) or null
+struct NodeArgs {        // k_px: hoisted x-part of layers >= 1
+  const float* xa;       // unused (kept for the shared main loop): folded rows or null
   long xaNodeStride, xaRowStride;
   int xaLen;
   const float* ident;    // identity slot rows: [row][Np][64] (+ n*64)
   long identRowStride;
   const float* g;        // mixed slots [N][rows][Ks][64]
   int Ks;
-  const float* w;        // fragment-ordered weights, per node
+  const float* w;        // fragment-ordered (32x32x2) x-part weights, per node
   long wNodeStride;
-  int rows;              // rows per node (B, or B*T for k_px)
-  int N, Np, T;
-  const float* px;       // hoisted pre-activations of this step: [N][rows][192], or null
-  float* raw;            // optional (B,N,128) pre-activation dump (unit entry point)
-  float* zh;             // k_gate: z*h out [rows][Np][64]
-  float* r;              // k_gate: r out / k_update: r in  [N][rows][64]
-  float* hstate;         // k_update: h in / h' out [rows][Np][64]
-  const float* bias;     // k_px: [N][192]
-  float* pxOut;          // k_px: [T][N][B][192]
-};
-
-struct ResArgs {
-  const float* x;        // x_t rows: x[b*xRowStride + n*C + c]
-  long xRowStride;
-  int C, Cpad;
-  const float* h;        // h' [B][Np][64]
-  float* hout;           // [B][Np][64]
-  float* seq;            // Seq_l at step t (or null): seq[b*seqRowStride + n*64 + o]
-  long seqRowStride;
-  const float* wg;       // fragment-ordered gate weight  [K/8][4][64][4]
-  const float* bg;       // (128)
-  const float* wu;       // fragment-ordered update weight [K/8][2][64][4]
-  const float* bu;       // (64)
-  const float* blend;    // &weights_gru[l][t] or null (plain GRUCell output)
-  int B, N, Np;
+  int rows;              // rows per node = B * (steps of the chunk)
+  int N, Np, B;          // B: batch rows per step (row -> (t, b), t-major)
+  const float* bias;     // [N][192]
+  float* pxOut;          // [Tc][N][B][192] slice of PX
 };
 
 struct HeadArgs {
@@ -84,7 +63,7 @@ struct HeadArgs {
   const float* w;        // fragment-ordered [T*8][NTc][64][4]
   const float* bias;
   float* out;
-  int B, T, N, Np, CH, od, NTc;
+  int B, T, N, Np, CH, od, NTc;   // seq is time-major [T][B][Np][64]
 };
 
 #endif

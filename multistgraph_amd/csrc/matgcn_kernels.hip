@@ -234,6 +234,31 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const float* __restrict__ s
   dst[idx] = src[(r * Np + n) * C + c];
 }
 
+// user (B, T, N, C) <-> padded time-major [T][B][Np][C]
+__global__ __launch_bounds__(256) void k_pack_seq_tm(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                     int T, int N, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)T * B * Np * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const int n = (idx / C) % Np;
+  const int b = (idx / ((size_t)C * Np)) % B;
+  const int t = idx / ((size_t)C * Np * B);
+  dst[idx] = (n < N) ? src[(((size_t)b * T + t) * N + n) * C + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_seq_tm(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                       int T, int N, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)B * T * N * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  const int n = (idx / C) % N;
+  const int t = (idx / ((size_t)C * N)) % T;
+  const int b = idx / ((size_t)C * N * T);
+  dst[idx] = src[(((size_t)t * B + b) * Np + n) * C + c];
+}
+
 // zero rows n in [N, Np) of a [rows][Np][C] buffer
 __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ buf, int rows, int N, int Np, int C) {
   const int per = (Np - N) * C;
@@ -487,72 +512,9 @@ __device__ __forceinline__ SegList make_segs(const NodeArgs& a, int n, const flo
   return S;
 }
 
-// ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) ------------------------------------------------------
-// zr = sigmoid(AGCN_gate([x|h])); z = zr[:, :H], r = zr[:, H:]; writes zh = z*h (next mix input) and r.
-__global__ __launch_bounds__(256) void k_gate(NodeArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Ws[4 * 4 * 64 * 4];
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
-  const int bt = w & 1, oh = w >> 1;
-  SegList S = make_segs(a, n, a.ident);
-  f32x16 acc[2];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-  node_mainloop<4, 2>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, oh * 2, bt, As, Ws, acc);
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int o = (oh * 2 + tt) * 32 + i;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int b = rowBase + bt * 32 + acc_row(r, half);
-      if (b >= a.rows) continue;
-      float v = acc[tt][r];
-      if (a.px) v += a.px[((size_t)n * a.rows + b) * 192 + o];
-      if (a.raw) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
-      const float s = sigmoid_f(v);
-      if (oh == 0) {
-        const size_t hi = ((size_t)b * a.Np + n) * 64 + o;
-        a.zh[hi] = s * a.ident[hi];
-      } else {
-        a.r[((size_t)n * a.rows + b) * 64 + (o - 64)] = s;
-      }
-    }
-  }
-}
-
-// ---- update AGCN + tanh + blend (MultiATGCN.py:125-127) ------------------------------------------------------
-// hc = tanh(AGCN_update([x|z*h])); h' = r*h + (1-r)*hc, written in place over h (each workgroup owns its rows).
-__global__ __launch_bounds__(256) void k_update(NodeArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Ws[4 * 2 * 64 * 4];
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
-  const int bt = w & 1, ot = w >> 1;
-  SegList S = make_segs(a, n, a.ident);  // ident = z*h here
-  f32x16 acc[1];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-  node_mainloop<2, 1>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, ot, bt, As, Ws, acc);
-  const int o = ot * 32 + i;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int b = rowBase + bt * 32 + acc_row(r, half);
-    if (b >= a.rows) continue;
-    float v = acc[0][r];
-    if (a.px) v += a.px[((size_t)n * a.rows + b) * 192 + 128 + o];
-    const float hc = tanhf(v);
-    const float rr = a.r[((size_t)n * a.rows + b) * 64 + o];
-    const size_t hi = ((size_t)b * a.Np + n) * 64 + o;
-    const float h = a.hstate[hi];
-    a.hstate[hi] = rr * h + (1.0f - rr) * hc;
-  }
-}
-
 // ---- hoisted x-part for layers >= 1: PX[t][n][b][0:192] = bias[n] + [x | mix(x)] . Wx[n] ---------------------
-// Same contraction with M = B*T rows per node (rows are (b,t) pairs, b-major), O = 128 (gate) | 64 (update).
+// Node-wise contraction with M = B*Tc rows per node (rows are (t,b) pairs of a chunk of steps, t-major),
+// O = 128 (gate) | 64 (update); 32x32x2 MFMA, A chunks and the weight chunk staged through LDS.
 __global__ __launch_bounds__(256) void k_px(NodeArgs a) {
   __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Ws[4 * 6 * 64 * 4];
@@ -566,7 +528,7 @@ __global__ __launch_bounds__(256) void k_px(NodeArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
   node_mainloop<6, 3>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, oh * 3, bt, As, Ws, acc);
-  const int B = a.rows / a.T;
+  const int B = a.B;   // rows are (t, b) pairs, t-major
 #pragma unroll
   for (int tt = 0; tt < 3; ++tt) {
     const int o = (oh * 3 + tt) * 32 + i;
@@ -575,121 +537,17 @@ __global__ __launch_bounds__(256) void k_px(NodeArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int row = rowBase + bt * 32 + acc_row(r, half);
       if (row >= a.rows) continue;
-      const int b = row / a.T, t = row - b * a.T;
+      const int t = row / B, b = row - t * B;
       a.pxOut[(((size_t)t * a.N + n) * B + b) * 192 + o] = acc[tt][r] + bias;
     }
   }
 }
 
 // =================================================================================================
-// 7. residual GRU cell + per-step blend (MultiATGCN.py:142-150, 205-208)
-// =================================================================================================
-// Dense GRU with shared weights on [x_t | h'] rows of one node (64 batch rows per workgroup):
-//   zr = sigmoid([x|h'] Wg + bg); cand = [x | z*h']; hc = tanh(cand Wu + bu); res = r*h' + (1-r)*hc
-//   h'' = g*h' + (1-g)*res, g = sigmoid(weights_gru[l][t]).  h'' goes to the state and to Seq[l][:, t].
-// The A operand [64][Cpad+64] lives in LDS (row stride = 4*odd floats -> conflict-free b128 reads); the shared
-// weights are read from L2 straight into B fragments (lane-linear float4).
-__global__ __launch_bounds__(256) void k_res_gru(ResArgs a) {
-  // static LDS sized for Cpad <= 64 (68.6 KB; gfx950 allows up to 160 KB per workgroup)
-  __shared__ __attribute__((aligned(16))) float AR[64 * 132];  // [64][sr]   x | h'
-  __shared__ __attribute__((aligned(16))) float ZH[64 * 68];   // [64][68]   z*h'
-  __shared__ __attribute__((aligned(16))) float R2[64 * 68];   // [64][68]   r
-  const int K = a.Cpad + 64;
-  const int sr = K + 4;  // K is a multiple of 8, so (K+4)/4 is odd: conflict-free ds_read_b128 rows
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
-  const int bt = w & 1, oh = w >> 1;
-  // stage x (zero padded to Cpad) and h'
-  for (int idx = tid; idx < 64 * a.Cpad; idx += 256) {
-    const int row = idx / a.Cpad, c = idx - row * a.Cpad;
-    const int b = rowBase + row;
-    float v = 0.f;
-    if (b < a.B && c < a.C) v = a.x[((size_t)b * a.xRowStride) + (size_t)n * a.C + c];
-    AR[row * sr + c] = v;
-  }
-  for (int idx = tid; idx < 64 * 16; idx += 256) {
-    const int row = idx >> 4, q = idx & 15;
-    const int b = rowBase + row;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < a.B) v = *reinterpret_cast<const float4*>(a.h + ((size_t)b * a.Np + n) * 64 + q * 4);
-    *reinterpret_cast<float4*>(&AR[row * sr + a.Cpad + q * 4]) = v;
-  }
-  __syncthreads();
-  // GEMM 1: zr pre-activation, wave tile 32 rows x 64 cols
-  f32x16 acc[2];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-  const int ng = K >> 3;
-  for (int g = 0; g < ng; ++g) {
-    const float4 a4 = *reinterpret_cast<const float4*>(&AR[(bt * 32 + i) * sr + g * 8 + half * 4]);
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const float4 w4 = *reinterpret_cast<const float4*>(a.wg + ((size_t)(g * 4 + oh * 2 + tt) * 64 + lane) * 4);
-      acc[tt] = MFMA32(a4.x, w4.x, acc[tt]);
-      acc[tt] = MFMA32(a4.y, w4.y, acc[tt]);
-      acc[tt] = MFMA32(a4.z, w4.z, acc[tt]);
-      acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
-    }
-  }
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int o = (oh * 2 + tt) * 32 + i;
-    const float bias = a.bg[o];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = bt * 32 + acc_row(r, half);
-      const float s = sigmoid_f(acc[tt][r] + bias);
-      if (oh == 0) ZH[row * 68 + o] = s * AR[row * sr + a.Cpad + o];
-      else R2[row * 68 + (o - 64)] = s;
-    }
-  }
-  __syncthreads();
-  // GEMM 2: candidate, wave tile 32 x 32 (wave w -> rows bt, cols oh*32)
-  f32x16 acc2;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  const int ngx = a.Cpad >> 3;
-  for (int g = 0; g < ng; ++g) {
-    const float* src = (g < ngx) ? &AR[(bt * 32 + i) * sr + g * 8 + half * 4]
-                                 : &ZH[(bt * 32 + i) * 68 + (g - ngx) * 8 + half * 4];
-    const float4 a4 = *reinterpret_cast<const float4*>(src);
-    const float4 w4 = *reinterpret_cast<const float4*>(a.wu + ((size_t)(g * 2 + oh) * 64 + lane) * 4);
-    acc2 = MFMA32(a4.x, w4.x, acc2);
-    acc2 = MFMA32(a4.y, w4.y, acc2);
-    acc2 = MFMA32(a4.z, w4.z, acc2);
-    acc2 = MFMA32(a4.w, w4.w, acc2);
-  }
-  const int o = oh * 32 + i;
-  const float bu = a.bu[o];
-  const float gate = a.blend ? sigmoid_f(a.blend[0]) : 0.f;  // g = sigmoid(weights_gru[l][t])
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = bt * 32 + acc_row(r, half);
-    const int b = rowBase + row;
-    if (b >= a.B) continue;
-    const float hc = tanhf(acc2[r] + bu);
-    const float hp = AR[row * sr + a.Cpad + o];
-    const float rr = R2[row * 68 + o];
-    const float res = rr * hp + (1.0f - rr) * hc;
-    const float hn = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
-    a.hout[((size_t)b * a.Np + n) * 64 + o] = hn;
-    if (a.seq) a.seq[((size_t)b * a.seqRowStride) + (size_t)n * 64 + o] = hn;
-  }
-}
-
-// state -> sequence copy used when the residual path is disabled in unit entry points (not on the hot path)
-__global__ __launch_bounds__(256) void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t count) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx < count) dst[idx] = src[idx];
-}
-
-// =================================================================================================
 // 8. output head (MultiATGCN.py:416-418): Conv2d(T -> out*od, (1,H)) == [B*N x T*H] . [T*H x CH]
 // =================================================================================================
-// One wave per (b, 32-node tile); A fragments straight from the padded sequence (each lane walks its node's
-// 256-byte rows), B = fragment-ordered conv weight from L2.  out[b][o][n][dd] with channel ch = o*od + dd.
+// One wave per (b, 32-node tile); A fragments straight from the padded time-major sequence [T][B][Np][64] (each
+// lane walks its node's 256-byte rows), B = fragment-ordered conv weight from L2.  out[b][o][n][dd] with channel ch = o*od + dd.
 __global__ __launch_bounds__(64) void k_head(HeadArgs a) {
   const int tilesPerB = (a.N + 31) >> 5;
   const int b = blockIdx.x / tilesPerB, n0 = (blockIdx.x % tilesPerB) * 32;
@@ -702,7 +560,7 @@ __global__ __launch_bounds__(64) void k_head(HeadArgs a) {
     for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
   const int nt = a.NTc;
   for (int t = 0; t < a.T; ++t) {
-    const float* rowp = a.seq + (((size_t)b * a.T + t) * a.Np + node) * 64 + half * 4;
+    const float* rowp = a.seq + (((size_t)t * a.B + b) * a.Np + node) * 64 + half * 4;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const float4 a4 = *reinterpret_cast<const float4*>(rowp + g * 8);

@@ -27,7 +27,10 @@ struct Node16Args {
   const float* s;        // [rows][Np][64]: h (gate / res-only) or z*h (update)
   const float* g;        // [N][rows][Ks][64] graph-mixed s
   const float* w;        // [N][nG][OT][64][4] recurrent rows of the node-adaptive weights (fragment order)
-  const float* px;       // [N][rows][192] hoisted pre-activation of this step (x rows + bias): gate 0:128, update 128:192
+  const float* px;       // [N][rows][192] hoisted pre-activation of this step (x rows + bias): gate 0:128, update
+                         // 128:192 - layers >= 1; null for layer 0, whose narrow x part is contracted in the kernel:
+  const float* xa;       // [N][rows][16*nGx] folded x rows of this step [x | mix_k(x) | 1 | 0..] (layer 0) or null
+  int nGx;               // k-groups of the x part (weights: groups nG .. nG+nGx-1 of the node's stream)
   int rows, N, Np, Ks;
   // gate
   float* zh;             // out [rows][Np][64]  z*h
@@ -107,6 +110,29 @@ __device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int K
   return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
 }
 
+// layer-0 x part: acc[rt] += XA[rows of tile rt][16 gx .. +16] . Wx[gx]; A fragments come straight from global
+// memory (a row of XA is 64*nGx bytes, a 16-row tile is contiguous), weights from the tail of the node's stream
+__device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, const float4* wx, int gStride, int i,
+                                         int kq, f32x4 (&acc)[4]) {
+  const int kx = 16 * a.nGx;
+  const float* base = a.xa + (size_t)n * a.rows * kx + kq * 4;
+  for (int gx = 0; gx < a.nGx; ++gx) {
+    const float4 wv = wx[(size_t)gx * gStride];
+    float4 av[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+      av[rt] = *reinterpret_cast<const float4*>(base + (size_t)min(rowBase + rt * 16 + i, a.rows - 1) * kx + gx * 16);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+  }
+}
+
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
 __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -116,21 +142,28 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + a.Ks);
   // weight stream of this wave: column tile w (of 8)
-  const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * nG * 8 + w) * 64 + lane;
+  const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
   stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
   float4 wr[N16_RING];
 #pragma unroll
   for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)min(r, nG - 1) * 8 * 64];
-  // accumulators start from the hoisted pre-activation (x rows + bias), fetched while the tile lands
+  // accumulators start from the hoisted pre-activation (x rows + bias), fetched while the tile lands;
+  // layer 0 instead contracts its narrow x part here, straight from global memory, before the tile is needed
   const int o = 16 * w + j;
   f32x4 acc[4];
+  if (a.px) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
-      acc[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + o];
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
+        acc[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + o];
+      }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    x_groups(a, n, rowBase, wp + (size_t)nG * 8 * 64, 8 * 64, j, kq, acc);
+  }
   __syncthreads();
   for (int g0 = 0; g0 < nG; g0 += N16_RING) {
 #pragma unroll
@@ -200,13 +233,14 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
   if (MODE != 2) {
     const int nG = 4 * (1 + a.Ks), nGh = nG >> 1;   // nG is even: each K half is nGh groups
     const int gBeg = kh * nGh;
-    const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * nG * 4 + ct) * 64 + lane;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
     stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
     float4 wr[N16_RING];
 #pragma unroll
     for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)(gBeg + min(r, nGh - 1)) * 4 * 64];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!a.px && kh == 0) x_groups(a, n, rowBase, wp + (size_t)nG * 4 * 64, 4 * 64, j, kq, acc);   // layer 0
     __syncthreads();
     for (int g0 = 0; g0 < nGh; g0 += N16_RING) {
 #pragma unroll
@@ -241,7 +275,7 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
-        pxv[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + 128 + o4];
+        pxv[rt][e] = a.px ? a.px[((size_t)n * a.rows + b) * 192 + 128 + o4] : 0.f;
         rv[rt][e] = a.r[((size_t)n * a.rows + b) * 64 + o4];
         hv[rt][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
       }
@@ -415,7 +449,7 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
 struct Prep16 {
   const float* E; const float* wpool; const float* wg;
   float* out;
-  int d, Ktot, I, O, iOfs, nG;
+  int d, Ktot, I, O, iOfs, nG, nGx;   // nGx: x groups that follow the nG recurrent groups in the node stream
 };
 __global__ __launch_bounds__(256) void k_prep_agcn16(Prep16 a) {
   const int n = blockIdx.y;
@@ -441,7 +475,7 @@ __global__ __launch_bounds__(256) void k_prep_agcn16(Prep16 a) {
     for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
     v[s] = a.wg ? acc * (expf(a.wg[k] - gmax) / gsum) : acc;
   }
-  *reinterpret_cast<float4*>(a.out + ((size_t)n * a.nG * OT * 64 + unit) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(a.out + ((size_t)n * (a.nG + a.nGx) * OT * 64 + unit) * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // nn.Linear weight (O, I) -> [g][ct][lane][4] of B[kk][o] = W[o][in(kk)]: rows kk < Cpad map to input kk (zero
@@ -464,58 +498,49 @@ __global__ __launch_bounds__(256) void k_prep_linear16(const float* __restrict__
   *reinterpret_cast<float4*>(out + (size_t)unit * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// ---- layer-0 hoisted x-part (tiny: K = Ktot*C0 + 1 <= 64): PX[t][n][b][o] = sum_j XA0[t][n][b][j] * W0x[n][j][o] ----
-// W0x rows: folded x rows (k, c) with softmax(weights_g) applied, then the bias row (XA0 carries a 1.0 there).
-struct PrepX0 {
+// ---- layer-0 x part of the node-adaptive weights, appended to the node's stream as groups nG .. nG+nGx-1 ------
+// folded rows kk = (k, c) -> g_k * sum_d E[n][d] * Wpool[d][k][c][o] (softmax(weights_g) applied), then the bias
+// row sum_d E[n][d] * bpool[d][o] at kk = Ktot*C0 (XA carries a 1.0 there), zeros after
+struct PrepX16 {
   const float* E; const float* wpool; const float* bpool; const float* wg;
-  float* out;            // [N][Kx][192]
-  int d, Ktot, I, O, C0, Kx, colOfs;
+  float* out;            // node stream base (float*), [n][nGtot][OT][64][4]
+  int d, Ktot, I, O, C0, nG, nGx;
 };
-__global__ __launch_bounds__(256) void k_prep_x0(PrepX0 a) {
+__global__ __launch_bounds__(256) void k_prep_x16(PrepX16 a) {
   const int n = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.Kx * a.O) return;
-  const int jrow = idx / a.O, o = idx - jrow * a.O;
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  const int OT = a.O >> 4;
+  if (unit >= a.nGx * OT * 64) return;
+  const int lane = unit & 63, ct = (unit >> 6) % OT, gx = (unit >> 6) / OT;
+  const int o = 16 * ct + (lane & 15);
   const float* e = a.E + (size_t)n * a.d;
+  float gmax = -3.0e38f, gsum = 0.f;
+  if (a.wg) {
+    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
+    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
+  }
   const int nx = a.Ktot * a.C0;
-  float val = 0.f;
-  if (jrow < nx) {
-    const int k = jrow / a.C0, c = jrow - k * a.C0;
-    const float* wp = a.wpool + ((size_t)k * a.I + c) * a.O + o;
-    const size_t dstride = (size_t)a.Ktot * a.I * a.O;
-    float acc = 0.f;
-    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
-    if (a.wg) {
-      float gmax = -3.0e38f, gsum = 0.f;
-      for (int kk = 0; kk < a.Ktot; ++kk) gmax = fmaxf(gmax, a.wg[kk]);
-      for (int kk = 0; kk < a.Ktot; ++kk) gsum += expf(a.wg[kk] - gmax);
-      acc *= expf(a.wg[k] - gmax) / gsum;
+  const size_t dstride = (size_t)a.Ktot * a.I * a.O;
+  float v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kk = 16 * gx + 4 * (lane >> 4) + s;
+    float val = 0.f;
+    if (kk < nx) {
+      const int k = kk / a.C0, c = kk - k * a.C0;
+      const float* wp = a.wpool + ((size_t)k * a.I + c) * a.O + o;
+      float acc = 0.f;
+      for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
+      val = a.wg ? acc * (expf(a.wg[k] - gmax) / gsum) : acc;
+    } else if (kk == nx) {
+      float acc = 0.f;
+      for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], acc);
+      val = acc;
     }
-    val = acc;
-  } else if (jrow == nx) {
-    float acc = 0.f;
-    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], acc);
-    val = acc;
+    v[s] = val;
   }
-  a.out[((size_t)n * a.Kx + jrow) * 192 + a.colOfs + o] = val;
-}
-
-// one workgroup (192 threads) per (node, step): thread o keeps its Kx weights in registers
-template <int KX>
-__global__ __launch_bounds__(192) void k_px0(const float* __restrict__ XA0, const float* __restrict__ W0x,
-                                             float* __restrict__ PX, int B, int N) {
-  const int n = blockIdx.x, t = blockIdx.y, o = threadIdx.x;
-  float wv[KX];
-#pragma unroll
-  for (int jj = 0; jj < KX; ++jj) wv[jj] = W0x[((size_t)n * KX + jj) * 192 + o];
-  const float* xa = XA0 + ((size_t)t * N + n) * B * KX;
-  float* dst = PX + ((size_t)t * N + n) * B * 192 + o;
-  for (int b = 0; b < B; ++b) {
-    float acc = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < KX; ++jj) acc = fmaf(xa[b * KX + jj], wv[jj], acc);
-    dst[(size_t)b * 192] = acc;
-  }
+  float* dst = a.out + ((size_t)n * (a.nG + a.nGx) * OT * 64 + (size_t)a.nG * OT * 64 + unit) * 4;
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 #endif
