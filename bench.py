@@ -15,8 +15,14 @@ every timed step, as the reference redoes it in every forward.
 
 Rank 0 prints ONE JSON line.  Two extra objects:
   roofline     - the dominant kernel (k_mix, the graph-mix GEMM): algorithmic FLOPs per launch divided by
-                 its average launch duration measured with HIP events in situ (one extra instrumented
-                 forward after the timed region), against the dense fp32 MFMA peak.
+                 its average launch duration measured with HIP events in situ, on the stream it is launched
+                 on, against the dense fp32 MFMA peak.  The timed steps run the layers' chains as a
+                 wavefront on several HIP streams, where a launch shares the chip with the other chain; so
+                 the headline figure comes from instrumented forwards with the wavefront switched off
+                 (matgcn_set_wavefront(0): same kernels, one stream - the launch duration is the kernel's
+                 own), and `in_wavefront` repeats it for an instrumented forward of the timed configuration.
+                 `traffic` is the HBM traffic per launch from the rocprofv3 PMC pass committed under
+                 profiles/ (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE), or null.
   cpu_baseline - the CPU oracle in its reference-faithful order (oracle/, kind "port"), timed on this
                  host's cores on the same workload (rank 0, N=1 only).
 """
@@ -92,15 +98,21 @@ def cpu_baseline(w, seed, x_np, model_state, df, pred_gpu):
                 seconds=dt, gpu_vs_cpu_max_norm_err=err), pred
 
 
-def in_situ_kernel_times(model, batch):
-    """One instrumented forward: HIP events around every kernel launch of the path, on its stream."""
+def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
+    """Instrumented forwards: HIP events around every kernel launch of the path, on its stream."""
     from multistgraph_amd import _lib
     lib = _lib.load()
-    cap = 4096
+    cap = 4096 * forwards
+    prev = lib.matgcn_set_wavefront(1 if wavefront else 0)
+    with torch.no_grad():
+        model.predict(batch)            # settle clocks / caches in this mode
+    torch.cuda.synchronize()
     _lib.check(lib.matgcn_profile_enable(63, cap), "matgcn_profile_enable")
     with torch.no_grad():
-        model.predict(batch)
+        for _ in range(forwards):
+            model.predict(batch)
     torch.cuda.synchronize()
+    lib.matgcn_set_wavefront(prev)
     ms = (C.c_float * cap)()
     kinds = (C.c_int * cap)()
     cnt = C.c_int()
@@ -122,6 +134,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache-prepared", action="store_true",
                     help="keep matgcn_prepare out of the timed steps (inference with frozen weights)")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run the timed steps too with the layer wavefront off (one stream): the configuration the "
+                         "kernel roofline is measured in; used for the rocprofv3 profile that must agree with it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +164,9 @@ def main():
     seed = 0
     model, df, cfg = build_model(w, device, seed)
     model.cache_prepared = bool(args.cache_prepared)
+    if args.serial_streams:
+        from multistgraph_amd import _lib
+        _lib.load().matgcn_set_wavefront(0)
     x_np, y_np = syn.make_batch_arrays(w["batch"], w["nodes"], w["out"], seed + rank, feat=2)
     batch = {"X": torch.from_numpy(x_np).to(device), "y": torch.from_numpy(y_np).to(device)}
 
@@ -166,33 +184,65 @@ def main():
             pred = model.predict(batch)
         sync_all()
         elapsed = time.perf_counter() - t0
+    units_local = w["batch"] * 24 * w["nodes"] * args.steps
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
+        from multistgraph_amd import sharding
+        value, elapsed = sharding.job_throughput(units_local, elapsed, device=device)   # sum units / max time
+    else:
+        value = units_local / elapsed
     units_per_step = w["batch"] * 24 * w["nodes"] * world
     ms_per_step = elapsed / args.steps * 1e3
-    value = units_per_step / (elapsed / args.steps)
 
     result = None
     if rank == 0:
         flops_unit = algorithmic_flops_per_unit(w["nodes"], out=w["out"])
         fwd_tflops = flops_unit * w["batch"] * 24 * w["nodes"] / (ms_per_step * 1e-3) / 1e12
-        times = in_situ_kernel_times(model, batch)
-        mix = times.get("k_mix", [])
         n, b, ks, h = w["nodes"], w["batch"], 4, 64
-        # launch order per layer: 1 hoisted pre-pass launch, then 2 in-step launches (h, z*h) per time step;
-        # the roofline line is about the in-step launches (columns = B*64)
-        prepass = {l * (1 + 2 * 24) for l in range(2)}
-        step_mix = [m for i, m in enumerate(mix) if i not in prepass]
+        mix_flops = 2.0 * ks * n * n * b * h                       # algorithmic, unpadded, per in-step launch
+
+        serial = in_situ_kernel_times(model, batch, wavefront=False, forwards=2)
+        conc = in_situ_kernel_times(model, batch, wavefront=True, forwards=1)
+        # In serial (layer-major) order the launches of one forward are: [fold0] + 48 step launches of layer 0,
+        # then per chunk of layer 1 one x-part launch followed by that chunk's step launches.
+        def split_steps(mix, forwards):
+            per = len(mix) // forwards
+            steps = []
+            for f in range(forwards):
+                one = mix[f * per:(f + 1) * per]
+                idx = 1                                   # skip the layer-0 fold launch
+                steps += one[idx:idx + 48]
+                idx += 48
+                t = 0
+                while t < 24 and idx < len(one):
+                    nt = 1 if t < 2 else (2 if t < 4 else 4)
+                    nt = min(nt, 24 - t)
+                    idx += 1                              # x-part chunk launch
+                    steps += one[idx:idx + 2 * nt]
+                    idx += 2 * nt
+                    t += nt
+            return steps
+        step_mix = split_steps(serial.get("k_mix", []), 2)
         mix_ms = statistics.mean(step_mix) if step_mix else float("nan")
-        mix_flops = 2.0 * ks * n * n * b * h                       # algorithmic, unpadded
         achieved = mix_flops / (mix_ms * 1e-3) / 1e12
+        conc_mix = conc.get("k_mix", [])
+        conc_ms = statistics.mean(conc_mix) if conc_mix else float("nan")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_k_mix.json")
+        if os.path.exists(tpath) and args.workload == "bm403" and w["batch"] == 64:
+            with open(tpath) as fh:
+                traffic = json.load(fh)
+        times = conc
         roofline = dict(bound="mfma", kernel="k_mix", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
-                        unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS, traffic=None,
+                        unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS,
+                        traffic=(traffic or {}).get("hbm_bytes_per_launch"),
+                        traffic_detail=traffic,
                         launches=len(step_mix), avg_launch_ms=mix_ms,
                         flops_per_launch=mix_flops,
+                        measured="HIP events around each launch, wavefront off (kernel alone on the chip)",
+                        in_wavefront=dict(avg_launch_ms=conc_ms, launches=len(conc_mix),
+                                          note="all k_mix launches of one forward of the timed configuration; "
+                                               "a launch shares the chip with the other layer's chain"),
+                        serial_kernel_ms_per_forward={k: round(sum(v) / 2, 4) for k, v in serial.items()},
                         whole_forward=dict(algorithmic_tflops=fwd_tflops,
                                            frac_mfma=fwd_tflops / PEAK_MFMA_F32_TFLOPS,
                                            algorithmic_gbs=algorithmic_bytes_per_unit() * units_per_step / world /
@@ -210,7 +260,8 @@ def main():
             "config": {"workload": w["desc"], "nodes": w["nodes"], "per_gpu_batch": w["batch"],
                        "global_batch": w["batch"] * world, "in_steps": 24, "out_steps": w["out"],
                        "parallelism": "batch shards, no data-path collective (dp%d)" % world,
-                       "prepare_in_timed_region": not args.cache_prepared},
+                       "prepare_in_timed_region": not args.cache_prepared,
+                       "layer_wavefront_streams": not args.serial_streams},
             "mae_at_12": mae12,
             "roofline": roofline,
         }

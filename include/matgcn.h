@@ -8,9 +8,10 @@
  * multistgraph_amd/model.py (the binding a maintainer would add is shown in INTEGRATION.md).
  *
  * Conventions
- *   - every function returns MATGCN_OK (0) or a negative matgcn_status; no exceptions, no
+ *   - every function returns MATGCN_OK (0) or a negative matgcn_status; no exceptions, no device
  *     allocation, no implicit synchronisation: work is enqueued on the caller's hipStream_t
- *     (passed as void*), and the caller owns every buffer including `prepared` and `workspace`.
+ *     (passed as void*) - internally forked onto library-owned streams that join back before the
+ *     call's last kernel - and the caller owns every buffer including `prepared` and `workspace`.
  *   - every pointer in matgcn_params / X / out / prepared / workspace is a DEVICE pointer to
  *     contiguous row-major fp32, 16-byte aligned (torch allocations are 256-byte aligned).
  *   - matgcn_dims is a plain host struct, read at call time.
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 1
+#define MATGCN_ABI_VERSION 2
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -156,6 +157,13 @@ int matgcn_encoder_fwd(const matgcn_dims* dims, const matgcn_params* params, con
 int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                        const float* seq, float* out, void* workspace, size_t workspace_bytes,
                        void* stream);
+
+/* ---- scheduling option ------------------------------------------------------------------------
+ * The encoder runs the recurrent chains of the layers as a wavefront on internal HIP streams (created once, on
+ * first use; forked from and joined back into the caller's stream with events, so the caller still sees one
+ * in-order stream).  matgcn_set_wavefront(0) serialises everything on the caller's stream instead - same kernels,
+ * same results; used to time one kernel alone.  Returns the previous setting. */
+int matgcn_set_wavefront(int enabled);
 
 /* ---- measurement hooks (bench.py; not on the hot path) ---------------------------------------
  * Time individual kernel launches in situ with HIP events recorded on the caller's stream.

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "matgcn_encoder_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, _P,
                                      C.c_size_t, _P]),
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "matgcn_profile_disable": (C.c_int, []),
@@ -98,8 +99,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 1:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 1" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 2:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 2" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

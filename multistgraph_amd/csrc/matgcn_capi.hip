@@ -178,6 +178,7 @@ struct Wavefront {
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
 };
 Wavefront g_wf;
+bool g_wavefront_on = true;   // matgcn_set_wavefront
 
 int wavefront_ready() {
   if (g_wf.ready) return MATGCN_OK;
@@ -350,7 +351,7 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
   RETURN_IF(node_kernels_ready(P.nodeLds));
   RETURN_IF(wavefront_ready());
   Wavefront& W = g_wf;
-  const bool multi = P.L > 1;
+  const bool multi = P.L > 1 && g_wavefront_on;
   if (multi) {
     HIP_OK(hipEventRecord(W.fork, c.s));
     for (int l = 1; l < P.L; ++l) {
@@ -360,7 +361,8 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
   }
   RETURN_IF(fold_x0(c, x0p, P.T, c.s));
   for (int l = 0; l < P.L; ++l) {
-    hipStream_t cs = (l == 0) ? c.s : W.chain[l];
+    hipStream_t cs = (l == 0 || !multi) ? c.s : W.chain[l];
+    hipStream_t xs = multi ? W.xpart[l] : c.s;
     RETURN_IF(zero_async(c.ws + P.oZHx[l], (long)P.B * P.Np * H, cs));
     if (P.Np != P.N) {
       hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)P.B * P.T * (P.Np - P.N) * H)), dim3(256), 0, cs,
@@ -382,10 +384,12 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
         if (nt > P.Tc) nt = P.Tc;
         if (t + nt > P.T) nt = P.T - t;
         nextChunk = t + nt;
-        HIP_OK(hipStreamWaitEvent(W.xpart[l], W.step[l - 1][t + nt - 1], 0));
-        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, W.xpart[l]));
-        HIP_OK(hipEventRecord(W.xdone[l][t], W.xpart[l]));
-        HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
+        if (multi) HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
+        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs));
+        if (multi) {
+          HIP_OK(hipEventRecord(W.xdone[l][t], xs));
+          HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
+        }
       }
       Node16Args res;
       if (l == 0)
@@ -395,16 +399,17 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
         fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, c.prm->weights_gru + (size_t)l * P.T + t,
                       seq + t * stepRows, &res);
       RETURN_IF(cell_step(c, l, t, nullptr, false, &res, cs));
-      if (l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
+      if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
     }
     if (finalsUser) {
       hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, cs, c.ws + P.oHx[l],
                          finalsUser + (size_t)l * P.B * P.N * H, P.B, P.N, P.Np, H);
       CHECK_LAUNCH();
     }
-    if (l > 0) HIP_OK(hipEventRecord(W.done[l], cs));
+    if (multi && l > 0) HIP_OK(hipEventRecord(W.done[l], cs));
   }
-  for (int l = 1; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(c.s, W.done[l], 0));   // join
+  if (multi)
+    for (int l = 1; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(c.s, W.done[l], 0));   // join
   return MATGCN_OK;
 }
 
@@ -485,6 +490,12 @@ int stage_single_step(const Ctx& c, int layer, const float* x, const float* h, b
 extern "C" {
 
 int matgcn_abi_version(void) { return MATGCN_ABI_VERSION; }
+
+int matgcn_set_wavefront(int enabled) {
+  const int prev = g_wavefront_on ? 1 : 0;
+  g_wavefront_on = enabled != 0;
+  return prev;
+}
 
 const char* matgcn_error_string(int status) {
   switch (status) {

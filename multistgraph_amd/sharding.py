@@ -1,0 +1,90 @@
+"""Batch sharding of the hot path over the GPUs of one node.
+
+The forward path shards on the batch axis only: parameters, supports and the ``prepared`` buffer are
+replicated, every rank runs its own slice of the global batch, and the forward needs **no collective**.
+``torch.distributed`` (backend ``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests) is used for the barrier /
+max-over-ranks timing of ``bench.py`` and for the one exchange a training step adds: a flat-bucket gradient
+all-reduce (15.5 MB fp32 at N=403 - one bucket, because xGMI rings are per-link bound and a single large
+message amortises the ring latency best).
+
+Nothing here touches the device path; it is plain host logic and is covered by world_size-2 gloo tests.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) rows of the global batch owned by ``rank``: contiguous, sizes differ by at most one
+    (the first ``global_batch % world`` ranks take the extra row)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank %d of world %d" % (rank, world))
+    if global_batch < 0:
+        raise ValueError("negative batch")
+    base, extra = divmod(global_batch, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_batch(batch: dict, rank: int, world: int) -> dict:
+    """Slice every tensor of a LibCity-style batch dict (``X``, ``y``) on axis 0."""
+    some = next(iter(batch.values()))
+    lo, hi = shard_bounds(int(some.shape[0]), rank, world)
+    return {k: v[lo:hi] for k, v in batch.items()}
+
+
+def gather_predictions(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+    """Concatenate the ranks' predictions in rank order (evaluation only; ragged shards allowed)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_bounds(global_batch, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    assert sizes[rank][1] - sizes[rank][0] == local.shape[0]
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+
+
+def job_throughput(units_local: float, seconds_local: float, device=None, group=None) -> Tuple[float, float]:
+    """Whole-job rate of a weak/strong-scaled run: sum of the ranks' units over the slowest rank's time
+    (the bench.py contract).  Returns (units_per_second, max_seconds)."""
+    t = torch.tensor([seconds_local, units_local], dtype=torch.float64, device=device)
+    tmax = t[:1].clone()
+    usum = t[1:].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(usum, op=dist.ReduceOp.SUM, group=group)
+    return float(usum.item() / tmax.item()), float(tmax.item())
+
+
+def flat_allreduce_mean_(tensors: Sequence[torch.Tensor], group=None) -> None:
+    """In-place mean over ranks of a list of tensors through ONE flat bucket (the gradient exchange of
+    data-parallel training; the backward kernels that would feed it are the next scope row)."""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+def replicas_in_sync(params: Iterable[torch.Tensor], group=None) -> bool:
+    """True when every rank holds bit-identical parameters (checksum all-reduce MIN/MAX)."""
+    acc = torch.zeros(2, dtype=torch.float64)
+    for p in params:
+        v = p.detach().double().cpu()
+        acc[0] += v.sum()
+        acc[1] += (v * v).sum()
+    lo, hi = acc.clone(), acc.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
