@@ -197,8 +197,13 @@ def main():
     if rank == 0:
         flops_unit = algorithmic_flops_per_unit(w["nodes"], out=w["out"])
         fwd_tflops = flops_unit * w["batch"] * 24 * w["nodes"] / (ms_per_step * 1e-3) / 1e12
-        n, b, ks, h = w["nodes"], w["batch"], 4, 64
-        mix_flops = 2.0 * ks * n * n * b * h                       # algorithmic, unpadded, per in-step launch
+        n, b, h = w["nodes"], w["batch"], 64
+        # supports the graph mix really multiplies by: diagonal ones (the similarity Laplacian is -I without
+        # static features) are folded into the node-adaptive weights at prepare time and never mixed
+        spec = model.spec
+        n_diag = bin(spec.diag_static_mask).count("1")
+        ks = (spec.n_first - n_diag) * (spec.cheb_k - 1)
+        mix_flops = 2.0 * ks * n * n * b * h                       # executed = algorithmic of the dense slots, unpadded
 
         serial = in_situ_kernel_times(model, batch, wavefront=False, forwards=2)
         conc = in_situ_kernel_times(model, batch, wavefront=True, forwards=1)
@@ -243,8 +248,13 @@ def main():
                                           note="all k_mix launches of one forward of the timed configuration; "
                                                "a launch shares the chip with the other layer's chain"),
                         serial_kernel_ms_per_forward={k: round(sum(v) / 2, 4) for k, v in serial.items()},
+                        dense_supports_mixed=ks, supports_folded_into_weights=n_diag * (spec.cheb_k - 1),
                         whole_forward=dict(algorithmic_tflops=fwd_tflops,
                                            frac_mfma=fwd_tflops / PEAK_MFMA_F32_TFLOPS,
+                                           executed_tflops=fwd_tflops * algorithmic_flops_per_unit(
+                                               w["nodes"], k_total=1 + ks, out=w["out"]) / flops_unit,
+                                           note="algorithmic = SURVEY section 8d formula (all K-1 supports dense); "
+                                                "executed = same formula with the folded diagonal supports removed",
                                            algorithmic_gbs=algorithmic_bytes_per_unit() * units_per_step / world /
                                            (ms_per_step * 1e-3) / 1e9,
                                            flops_per_unit=flops_unit),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 2
+#define MATGCN_ABI_VERSION 3
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -66,6 +66,9 @@ typedef struct matgcn_dims {
   int32_t scale_by_g;   /* 1 iff adjtype == 'multi': stack *= softmax(weights_g) (:102-103) */
   int32_t n_heads;      /* temporal heads fused (2 if output_window < 6 else 4, :371-393) */
   int32_t n_ts;         /* len(weight_tsg) = len_ts (:328-332) */
+  int32_t diag_static_mask; /* bit s set: static support s is a diagonal matrix (host-checked, e.g. the
+                           * similarity Laplacian -I without static features, :244-250).  Such supports are
+                           * folded into the identity slot of the node-adaptive weights and never mixed. */
   int32_t head_begin[MATGCN_MAX_HEADS]; /* first X step of head h (trend head never advances) */
   int32_t ext_src[MATGCN_MAX_EXT];      /* X channel copied into encoder channel out_dim+j */
 } matgcn_dims;
@@ -107,8 +110,8 @@ int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes);
 
 /* Where the transposed support stack lives inside `prepared` (for tests / debugging):
  * out[0] = float offset, out[1] = leading dimension, out[2] = padded node count Np,
- * out[3] = number of non-identity supports Ks.  Element S_k[n][m] is at
- * prepared[out[0] + m*out[1] + k*Np + n]. */
+ * out[3] = number of DENSE non-identity slots Ks (diagonal supports are folded away, in stack order
+ * otherwise).  Element S_k[n][m] of dense slot k is at prepared[out[0] + m*out[1] + k*Np + n]. */
 int matgcn_supports_layout(const matgcn_dims* dims, int64_t out[4]);
 
 /* ---- parameter-only work, once per parameter update ----------------------------------------

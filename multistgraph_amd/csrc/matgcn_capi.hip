@@ -6,6 +6,8 @@
 // the recurrence ("schedule").
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/matgcn.h"
@@ -25,7 +27,10 @@ inline long rup(long v, long m) { return (v + m - 1) / m * m; }
 
 // ---- derived sizes ---------------------------------------------------------------------------------
 struct Plan {
-  int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od, Tc;
+  int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od, Tc;   // Ks/Ktot: DENSE slots (+ identity)
+  int per, KtotOrig, nDenseFirst;
+  int denseFirst[4];          // first-order supports that are mixed (index into [adaptive?, statics...])
+  int diagFirst[4], nDiagFirst;
   int nc0, nc0p;              // layer-0 plain-matrix columns (B*T*C0) and padded to 64
   int NpC;                    // N rounded up to 64: plain N x N scratch leading dimension
   // prepared offsets (floats)
@@ -68,9 +73,19 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->d = D->embed_dim; P->CH = D->out_channels; P->od = D->out_dim;
   P->Np = (int)rup(P->N, 16);
   P->NpC = (int)rup(P->N, 64);
-  P->nFirst = (D->adp_mode != MATGCN_ADP_NONE ? 1 : 0) + D->n_static;
+  const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
+  P->nFirst = adp + D->n_static;
   if (P->nFirst < 1) return MATGCN_ERR_BAD_ARG;
-  P->Ks = P->nFirst * (D->cheb_k - 1);
+  P->per = D->cheb_k - 1;
+  P->KtotOrig = 1 + P->nFirst * P->per;
+  if (P->KtotOrig > MATGCN_MAX_STACK) return MATGCN_ERR_UNSUPPORTED;
+  if (D->diag_static_mask < 0 || D->diag_static_mask >= (1 << D->n_static)) return MATGCN_ERR_BAD_ARG;
+  for (int f = 0; f < P->nFirst; ++f) {
+    const bool diag = f >= adp && ((D->diag_static_mask >> (f - adp)) & 1);
+    if (diag) P->diagFirst[P->nDiagFirst++] = f;
+    else P->denseFirst[P->nDenseFirst++] = f;
+  }
+  P->Ks = P->nDenseFirst * P->per;
   P->Ktot = P->Ks + 1;
   P->Mp = (int)rup((long)P->Ks * P->Np, 64);
   P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 16);   // folded x rows of layer 0 (+ bias row), whole k-groups
@@ -147,9 +162,19 @@ struct ProfScope {  // records an event pair around one launch when that kernel 
 };
 
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? MATGCN_OK : MATGCN_ERR_LAUNCH; }
+// MATGCN_DEBUG_SYNC=1: synchronise after every checked launch and name the source line (fault hunting only)
+inline bool debug_sync() {
+  static const int on = []() { const char* e = getenv("MATGCN_DEBUG_SYNC"); return e && e[0] == '1' ? 1 : 0; }();
+  return on != 0;
+}
 #define CHECK_LAUNCH()                                   \
   do {                                                   \
     if (hipGetLastError() != hipSuccess) return MATGCN_ERR_LAUNCH; \
+    if (debug_sync()) {                                  \
+      fprintf(stderr, "[matgcn] launch at line %d ...", __LINE__); fflush(stderr); \
+      const hipError_t e__ = hipDeviceSynchronize();     \
+      fprintf(stderr, " %s\n", hipGetErrorString(e__)); fflush(stderr); \
+    }                                                    \
   } while (0)
 #define RETURN_IF(x)            \
   do {                          \
@@ -201,6 +226,7 @@ int wavefront_ready() {
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
                float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s) {
+  if (Ks <= 0 || rowsM <= 0) return MATGCN_OK;   // every support folded away: nothing to mix
   MixArgs a;
   a.St = St; a.ldS = P.Mp; a.X = X; a.xTileStride = xTileStride; a.ldX = ldX;
   a.out = out; a.sN = sN; a.sK = sK; a.sT = sT;
@@ -542,13 +568,13 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   if (prepared_bytes < (size_t)P.preparedFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   RETURN_IF(check_layer_params(dims, params));
   if (dims->adp_mode == MATGCN_ADP_UNI && (!params->node_vec1 || !params->node_vec2)) return MATGCN_ERR_NULL;
-  if (dims->n_static > 0 && !params->static_supports) return MATGCN_ERR_NULL;
+  if (dims->n_static > 0 && !params->static_supports) return MATGCN_ERR_NULL;   // also the diagonal ones
   if (!params->end_conv_weight || !params->end_conv_bias) return MATGCN_ERR_NULL;
   float* prep = (float*)prepared;
   float* St = prep + P.oSt;
   const int per = dims->cheb_k - 1;  // stack slots per first-order support
-  RETURN_IF(zero_async(St, (long)P.Np * P.Mp, c.s));
-  const bool cheb = dims->cheb_k > 2;
+  if (P.Mp > 0) RETURN_IF(zero_async(St, (long)P.Np * P.Mp, c.s));
+  const bool cheb = dims->cheb_k > 2 && P.nDenseFirst > 0;
   float* plainA = cheb ? prep + P.oPlainA : nullptr;  // T_{k-1}
   float* plainB = cheb ? prep + P.oPlainB : nullptr;  // T_{k-2} / product scratch
   float* plainC = cheb ? prep + P.oPlainC : nullptr;
@@ -558,8 +584,9 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     RETURN_IF(zero_async(plainC, (long)P.Np * P.NpC, c.s));
   }
   const dim3 tgrid((unsigned)((P.N + 31) / 32), (unsigned)((P.N + 31) / 32));
-  for (int f = 0; f < P.nFirst; ++f) {
-    const int slot0 = f * per;
+  for (int fd = 0; fd < P.nDenseFirst; ++fd) {   // diagonal supports are folded into the weights instead
+    const int f = P.denseFirst[fd];
+    const int slot0 = fd * per;
     const int col0 = slot0 * P.Np;
     const bool adaptive = (dims->adp_mode != MATGCN_ADP_NONE) && f == 0;
     if (adaptive) {
@@ -589,39 +616,57 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     }
   }
   // node-adaptive weights
-  const unsigned N = (unsigned)P.N;
+  StackMap map;
+  memset(&map, 0, sizeof(map));
+  map.KtotOrig = P.KtotOrig; map.N = P.N;
+  map.keepK[0] = 0; map.nKeep = 1;
+  for (int fd = 0; fd < P.nDenseFirst; ++fd)
+    for (int j = 0; j < per; ++j) map.keepK[map.nKeep++] = 1 + P.denseFirst[fd] * per + j;
+  {
+    const int adp = dims->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
+    for (int q = 0; q < P.nDiagFirst; ++q)
+      for (int j = 0; j < per; ++j) {
+        map.diagK[map.nDiag] = 1 + P.diagFirst[q] * per + j;
+        map.diagOrder[map.nDiag] = j + 1;
+        map.diagSrc[map.nDiag] = params->static_supports + (size_t)(P.diagFirst[q] - adp) * P.N * P.N;
+        ++map.nDiag;
+      }
+  }
+  const unsigned nodeGroups = (unsigned)((P.N + PREP_NB - 1) / PREP_NB);
   for (int l = 0; l < P.L; ++l) {
     const int I = P.Cl[l] + H;
     for (int part = 0; part < 2; ++part) {  // 0 gate (O=128), 1 update (O=64)
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
-      float* stream = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
-      {  // recurrent (h) rows, 16x16x4 fragment order
-        Prep16 q;
-        q.E = params->node_emb; q.wpool = ap.weights_pool; q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-        q.out = stream;
-        q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.iOfs = P.Cl[l]; q.nG = 4 * P.Ktot; q.nGx = P.nGx[l];
-        hipLaunchKernelGGL(k_prep_agcn16, dim3(blocks_for((size_t)q.nG * (O / 16) * 64), N), dim3(256), 0, c.s, q);
-        CHECK_LAUNCH();
-      }
+      const int nG = 4 * P.Ktot;
+      PrepStream q;
+      memset(&q, 0, sizeof(q));
+      q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
+      q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
+      q.d = P.d; q.I = I; q.O = O; q.N = P.N; q.C0 = P.C0; q.map = map;
+      // recurrent (h) rows, 16x16x4 fragment order: groups 0..nG-1 of the node stream
+      q.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
+      q.nodeStride = (long)(nG + P.nGx[l]) * 16 * O;
+      q.baseOfs = 0; q.kind = 0; q.iOfs = P.Cl[l]; q.groups = nG;
+      hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
+                         c.s, q);
+      CHECK_LAUNCH();
       if (l == 0) {  // folded x rows + bias row, appended to the node stream
-        PrepX16 q;
-        q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
-        q.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-        q.out = stream; q.d = P.d; q.Ktot = P.Ktot; q.I = I; q.O = O; q.C0 = P.C0;
-        q.nG = 4 * P.Ktot; q.nGx = P.nGx[0];
-        hipLaunchKernelGGL(k_prep_x16, dim3(blocks_for((size_t)q.nGx * (O / 16) * 64), N), dim3(256), 0, c.s, q);
+        q.baseOfs = (long)nG * 16 * O; q.kind = 1; q.iOfs = 0; q.groups = P.nGx[0];
+        hipLaunchKernelGGL(k_prep_stream<1>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
+                           c.s, q);
         CHECK_LAUNCH();
       } else {
         // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
-        PrepAgcn a;
-        memset(&a, 0, sizeof(a));
-        a.E = params->node_emb; a.wpool = ap.weights_pool; a.bpool = ap.bias_pool;
-        a.wg = dims->scale_by_g ? ap.weights_g : nullptr;
-        a.d = P.d; a.Ktot = P.Ktot; a.I = I; a.O = O; a.OTsrc = O / 32;
-        a.out = prep + P.oWx[l]; a.nodeStride = P.wxStride; a.OTdst = 6; a.otOfs = part == 0 ? 0 : 4;
-        a.mode = 0; a.Cw = H; a.iOfs = 0; a.rows = P.Ktot * H; a.streamOfs = 0;
-        hipLaunchKernelGGL(k_prep_agcn, dim3(blocks_for((size_t)(a.rows / 8) * a.OTsrc * 64), N), dim3(256), 0, c.s, a);
+        q.out = prep + P.oWx[l]; q.nodeStride = P.wxStride; q.baseOfs = 0;
+        q.kind = 2; q.iOfs = 0; q.groups = P.Ktot * H / 8; q.OTdst = 6; q.otOfs = part == 0 ? 0 : 4;
+        if (debug_sync())
+          fprintf(stderr, "[matgcn] kind2: out %p..%p E %p wpool %p..%p diag0 %p wg %p prep %p..%p\n", (void*)q.out,
+                  (void*)(q.out + (size_t)P.N * q.nodeStride), (void*)q.E, (void*)q.wpool,
+                  (void*)(q.wpool + (size_t)P.d * P.KtotOrig * I * O), (void*)map.diagSrc[0], (void*)q.wg, (void*)prep,
+                  (void*)(prep + P.preparedFloats));
+        hipLaunchKernelGGL(k_prep_stream<2>, dim3(blocks_for((size_t)q.groups * (O / 32) * 64), nodeGroups), dim3(256), 0,
+                           c.s, q);
         CHECK_LAUNCH();
         hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, c.s, params->node_emb,
                            ap.bias_pool, P.d, O, P.N, prep + P.oBx[l], 192, part == 0 ? 0 : 128);

@@ -4,21 +4,41 @@
 #include <stddef.h>
 #include <stdint.h>
 
-struct PrepAgcn {
-  const float* E;      // node_emb (N, d)
-  const float* wpool;  // (d, Ktot, I, O)
-  const float* bpool;  // (d, O)
-  const float* wg;     // weights_g (Ktot) or null (no stack scaling)
+#define MATGCN_MAX_STACK 16   /* entries of the reference's support stack (identity included) this build maps */
+
+// How the reference's support stack [I, S_1 orders.., S_2 orders.., ...] (MultiATGCN.py:94-103) maps onto what the
+// kernels see.  Supports that are diagonal matrices (e.g. the similarity Laplacian -I when there are no static
+// features, MultiATGCN.py:244-250) need no graph mix at all: S x = diag(s) x, so their weight rows are folded into
+// the identity slot, scaled per node by the Chebyshev value t_order(s_n), and they disappear from the stack.
+struct StackMap {
+  int KtotOrig;                       // entries of weights_g / weights_pool along k
+  int nKeep;                          // 1 (identity) + dense slots
+  int keepK[MATGCN_MAX_STACK];        // original k of every kept slot (keepK[0] = 0)
+  int nDiag;                          // folded (diagonal) slots
+  int diagK[MATGCN_MAX_STACK];        // original k of every folded slot
+  int diagOrder[MATGCN_MAX_STACK];    // Chebyshev order of that slot (1 = the support itself)
+  const float* diagSrc[MATGCN_MAX_STACK];  // (N,N) first-order support whose diagonal feeds it
+  int N;
+};
+
+// One launch of k_prep_stream writes, for a group of nodes, one piece of their weight streams:
+//   val(n, row, o) = sum_d E[n][d] * g_k * Wpool[d][k][i][o]   with (k, i) decoded from the row by `kind`
+struct PrepStream {
+  const float* E;        // node_emb (N, d)
+  const float* wpool;    // (d, KtotOrig, I, O)
+  const float* bpool;    // (d, O) - bias row of kind 1
+  const float* wg;       // weights_g (KtotOrig) or null (no stack scaling)
   float* out;
-  long nodeStride;     // floats between nodes in the destination stream
-  long streamOfs;      // float offset of this part inside a node's stream
-  int d, Ktot, I, O;
-  int iOfs;            // first input channel of this part inside I
-  int mode;            // 0: rows j -> (k = j / Cw, i = iOfs + j % Cw); 1: folded x rows + bias row
-  int Cw;              // channels per support slot in this part
-  int rows;            // padded row count (multiple of 8)
-  int OTsrc;           // O / 32
-  int OTdst, otOfs;    // tiles per fragment row in the destination, first tile of this part
+  long nodeStride;       // floats between nodes in the destination
+  long baseOfs;          // float offset of this piece inside a node's stream
+  int d, I, O, N;
+  int kind;              // 0: recurrent rows, 16x16x4 order   rows kk -> slot kk/64, channel iOfs + kk%64
+                         // 1: layer-0 folded x rows, 16x16x4 order   rows kk -> slot kk/C0, channel kk%C0, then bias row
+                         // 2: x rows of layers >= 1, 32x32x2 order (k_px)   rows j -> slot j/64, channel iOfs + j%64
+  int iOfs, C0;
+  int groups;            // k-groups (kinds 0/1: of 16 rows; kind 2: of 8 rows)
+  int OTdst, otOfs;      // kind 2: tiles per fragment row in the destination, first tile of this piece
+  StackMap map;
 };
 
 struct FuseArgs {

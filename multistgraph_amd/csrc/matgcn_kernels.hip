@@ -122,59 +122,129 @@ __global__ __launch_bounds__(256) void k_cheb_combine(const float* __restrict__ 
 // 2. node-adaptive weights in MFMA fragment order
 // =================================================================================================
 // W[n][k][i][o] = g_k * sum_d E[n][d] * Wpool[d][k][i][o], bias[n][o] = sum_d E[n][d] * bpool[d][o]
-// (MultiATGCN.py:102-105; g = softmax(weights_g) is folded here instead of scaling the stack).
-// One thread produces the float4 a lane feeds to 4 consecutive MFMAs: rows j = 8*jg + 4*(lane>>5) + {0..3},
-// column o = 32*tile + (lane&31).
-__global__ __launch_bounds__(256) void k_prep_agcn(PrepAgcn a) {
-  const int n = blockIdx.y;
+// (MultiATGCN.py:102-105; g = softmax(weights_g) is folded here instead of scaling the stack; diagonal supports
+// are folded into the identity slot, see StackMap).  One thread produces, for PREP_NB consecutive nodes, the
+// float4 a lane feeds to 4 consecutive MFMAs, so every pool element it reads serves PREP_NB nodes.
+#define PREP_NB 8
+
+// Chebyshev value t_order(s): t_0 = 1, t_1 = s, t_j = 2 s t_{j-1} - t_{j-2}   (MultiATGCN.py:98-99 on a diagonal)
+__device__ __forceinline__ float cheb_scalar(float s, int order) {
+  float t0 = 1.f, t1 = s;
+  for (int j = 2; j <= order; ++j) { const float t2 = 2.f * s * t1 - t0; t0 = t1; t1 = t2; }
+  return t1;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
+  const int nBase = blockIdx.y * PREP_NB;
   const int unit = blockIdx.x * 256 + threadIdx.x;
-  const int units = (a.rows >> 3) * a.OTsrc * 64;
-  if (unit >= units) return;
-  const int lane = unit & 63;
-  const int ot = (unit >> 6) % a.OTsrc;
-  const int jg = (unit >> 6) / a.OTsrc;
-  const int o = ot * 32 + (lane & 31);
-  const float* e = a.E + (size_t)n * a.d;
-  // softmax over the Ktot stack weights (tiny)
-  float gmax = -3.0e38f, gsum = 0.f;
-  if (a.wg) {
-    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
-    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
-  }
-  float v[4];
+  const int OT = KIND == 2 ? (a.O >> 5) : (a.O >> 4);
+  if (unit >= a.groups * OT * 64) return;
+  const int lane = unit & 63, ct = (unit >> 6) % OT, g = (unit >> 6) / OT;
+  const int o = KIND == 2 ? 32 * ct + (lane & 31) : 16 * ct + (lane & 15);
+  // decode the 4 rows of this lane's float4
+  int slot[4], chan[4];   // kept slot (-1: zero row, -2: bias row) and input channel
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int j = jg * 8 + 4 * (lane >> 5) + q;
-    float val = 0.f;
-    if (a.mode == 0) {
-      const int k = j / a.Cw, i = a.iOfs + (j - k * a.Cw);
-      if (k < a.Ktot) {
-        const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
-        const size_t dstride = (size_t)a.Ktot * a.I * a.O;
-        float s = 0.f;
-        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], wp[dd * dstride], s);
-        val = a.wg ? s * (expf(a.wg[k] - gmax) / gsum) : s;
-      }
+  for (int s = 0; s < 4; ++s) {
+    if (KIND == 0) {
+      const int kk = 16 * g + 4 * (lane >> 4) + s;
+      slot[s] = kk >> 6; chan[s] = a.iOfs + (kk & 63);
+    } else if (KIND == 1) {
+      const int kk = 16 * g + 4 * (lane >> 4) + s;
+      const int nx = a.map.nKeep * a.C0;
+      if (kk < nx) { slot[s] = kk / a.C0; chan[s] = kk - slot[s] * a.C0; }
+      else { slot[s] = kk == nx ? -2 : -1; chan[s] = 0; }
     } else {
-      const int nx = a.Ktot * a.Cw;  // folded x rows, then the bias row, then zero padding
-      if (j < nx) {
-        const int k = j / a.Cw, i = j - k * a.Cw;
-        const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
-        const size_t dstride = (size_t)a.Ktot * a.I * a.O;
-        float s = 0.f;
-        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], wp[dd * dstride], s);
-        val = a.wg ? s * (expf(a.wg[k] - gmax) / gsum) : s;
-      } else if (j == nx) {
-        float s = 0.f;
-        for (int dd = 0; dd < a.d; ++dd) s = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], s);
-        val = s;
+      const int jj = 8 * g + 4 * (lane >> 5) + s;
+      slot[s] = jj >> 6; chan[s] = a.iOfs + (jj & 63);
+    }
+  }
+  // softmax over the stack weights (tiny)
+  float gmax = -3.0e38f, gsum = 1.f;
+  if (a.wg) {
+    gsum = 0.f;
+    for (int k = 0; k < a.map.KtotOrig; ++k) gmax = fmaxf(gmax, a.wg[k]);
+    for (int k = 0; k < a.map.KtotOrig; ++k) gsum += expf(a.wg[k] - gmax);
+  }
+  auto gk = [&](int k) { return a.wg ? expf(a.wg[k] - gmax) / gsum : 1.f; };
+  const size_t dstride = (size_t)a.map.KtotOrig * a.I * a.O;
+  float acc[PREP_NB][4];
+#pragma unroll
+  for (int b = 0; b < PREP_NB; ++b)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[b][s] = 0.f;
+  // kept slots (and the bias row): one pool offset per row
+  size_t rofs[4];
+  float scale[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    rofs[s] = 0; scale[s] = 0.f;
+    if (slot[s] >= 0) {
+      const int k = a.map.keepK[slot[s]];
+      rofs[s] = ((size_t)k * a.I + chan[s]) * a.O + o;
+      scale[s] = gk(k);
+    } else if (slot[s] == -2) {
+      scale[s] = 1.f;
+    }
+  }
+  for (int dd = 0; dd < a.d; ++dd) {
+    float pv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float v = 0.f;
+      if (slot[s] >= 0) v = a.wpool[(size_t)dd * dstride + rofs[s]];
+      else if (slot[s] == -2) v = a.bpool[(size_t)dd * a.O + o];
+      pv[s] = v * scale[s];
+    }
+#pragma unroll
+    for (int b = 0; b < PREP_NB; ++b) {
+      const float e = a.E[(size_t)min(nBase + b, a.N - 1) * a.d + dd];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[b][s] = fmaf(e, pv[s], acc[b][s]);
+    }
+  }
+  // folded diagonal supports: identity-slot rows also take t_order(s_n) * g_k * W[n][k]
+  const bool anyIdent = slot[0] == 0 || slot[1] == 0 || slot[2] == 0 || slot[3] == 0;
+  if (anyIdent) {
+    for (int q = 0; q < a.map.nDiag; ++q) {
+      const int k = a.map.diagK[q];
+      const float gq = gk(k);
+      float part[PREP_NB][4];
+#pragma unroll
+      for (int b = 0; b < PREP_NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) part[b][s] = 0.f;
+      for (int dd = 0; dd < a.d; ++dd) {
+        float pv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          pv[s] = slot[s] == 0 ? a.wpool[(size_t)dd * dstride + ((size_t)k * a.I + chan[s]) * a.O + o] : 0.f;
+#pragma unroll
+        for (int b = 0; b < PREP_NB; ++b) {
+          const float e = a.E[(size_t)min(nBase + b, a.N - 1) * a.d + dd];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) part[b][s] = fmaf(e, pv[s], part[b][s]);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < PREP_NB; ++b) {
+        const int n = min(nBase + b, a.N - 1);
+        const float t = gq * cheb_scalar(a.map.diagSrc[q][(size_t)n * (a.map.N + 1)], a.map.diagOrder[q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[b][s] = fmaf(t, part[b][s], acc[b][s]);
       }
     }
-    v[q] = val;
   }
-  float* dst = a.out + (size_t)n * a.nodeStride + a.streamOfs +
-               ((size_t)(jg * a.OTdst + a.otOfs + ot) * 64 + lane) * 4;
-  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  size_t frag;
+  if (KIND == 2) frag = ((size_t)(g * a.OTdst + a.otOfs + ct) * 64 + lane) * 4;
+  else frag = (size_t)unit * 4;
+#pragma unroll
+  for (int b = 0; b < PREP_NB; ++b) {
+    const int n = nBase + b;
+    if (n < a.N)
+      *reinterpret_cast<float4*>(a.out + (size_t)n * a.nodeStride + a.baseOfs + frag) =
+          make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+  }
 }
 
 // bias[n][colOfs + o] = E[n] . bpool[:, o]   (hoisted-PX layers)

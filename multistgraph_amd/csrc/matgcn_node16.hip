@@ -80,6 +80,10 @@ __device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int 
   const int spr = 16 * a.Ks;
   const float4* gsrc = reinterpret_cast<const float4*>(a.g + (size_t)n * a.rows * spr * 4);
   const int pA = q ^ (rA & 15), pB = q ^ (rB & 15);
+  if (a.Ks == 0) {   // no dense support left (all folded): only the s slots
+    *reinterpret_cast<float4*>(&Hs[(rA * 16 + pA) * 4]) = keep4(vA, hA);
+    *reinterpret_cast<float4*>(&Hs[(rB * 16 + pB) * 4]) = keep4(vB, hB);
+  }
   for (int k0 = 0; k0 < a.Ks; k0 += 4) {
     float4 vAk[4], vBk[4];
 #pragma unroll
@@ -443,40 +447,7 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
     }
 }
 
-// ---- parameter-only: node-adaptive recurrent weights in 16x16x4 B-fragment order ----------------------------
-// out[n][g][ct][lane][s] = g_k * sum_d E[n][d] * Wpool[d][k][C_l + i][16ct + (lane&15)],  kk = 16g + 4(lane>>4) + s,
-// k = kk / 64, i = kk % 64  (MultiATGCN.py:102-105; softmax(weights_g) folded in)
-struct Prep16 {
-  const float* E; const float* wpool; const float* wg;
-  float* out;
-  int d, Ktot, I, O, iOfs, nG, nGx;   // nGx: x groups that follow the nG recurrent groups in the node stream
-};
-__global__ __launch_bounds__(256) void k_prep_agcn16(Prep16 a) {
-  const int n = blockIdx.y;
-  const int unit = blockIdx.x * 256 + threadIdx.x;
-  const int OT = a.O >> 4;
-  if (unit >= a.nG * OT * 64) return;
-  const int lane = unit & 63, ct = (unit >> 6) % OT, g = (unit >> 6) / OT;
-  const int o = 16 * ct + (lane & 15);
-  const float* e = a.E + (size_t)n * a.d;
-  float gmax = -3.0e38f, gsum = 0.f;
-  if (a.wg) {
-    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
-    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
-  }
-  float v[4];
-  const size_t dstride = (size_t)a.Ktot * a.I * a.O;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int kk = 16 * g + 4 * (lane >> 4) + s;
-    const int k = kk >> 6, i = a.iOfs + (kk & 63);
-    const float* wp = a.wpool + ((size_t)k * a.I + i) * a.O + o;
-    float acc = 0.f;
-    for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
-    v[s] = a.wg ? acc * (expf(a.wg[k] - gmax) / gsum) : acc;
-  }
-  *reinterpret_cast<float4*>(a.out + ((size_t)n * (a.nG + a.nGx) * OT * 64 + unit) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-}
+// ---- parameter-only: the node-adaptive weight streams are written by k_prep_stream (matgcn_kernels.hip) ----
 
 // nn.Linear weight (O, I) -> [g][ct][lane][4] of B[kk][o] = W[o][in(kk)]: rows kk < Cpad map to input kk (zero
 // beyond C), rows kk >= Cpad map to input C + (kk - Cpad)
@@ -496,51 +467,6 @@ __global__ __launch_bounds__(256) void k_prep_linear16(const float* __restrict__
     v[s] = (in >= 0 && in < I) ? W[(size_t)o * I + in] : 0.f;
   }
   *reinterpret_cast<float4*>(out + (size_t)unit * 4) = make_float4(v[0], v[1], v[2], v[3]);
-}
-
-// ---- layer-0 x part of the node-adaptive weights, appended to the node's stream as groups nG .. nG+nGx-1 ------
-// folded rows kk = (k, c) -> g_k * sum_d E[n][d] * Wpool[d][k][c][o] (softmax(weights_g) applied), then the bias
-// row sum_d E[n][d] * bpool[d][o] at kk = Ktot*C0 (XA carries a 1.0 there), zeros after
-struct PrepX16 {
-  const float* E; const float* wpool; const float* bpool; const float* wg;
-  float* out;            // node stream base (float*), [n][nGtot][OT][64][4]
-  int d, Ktot, I, O, C0, nG, nGx;
-};
-__global__ __launch_bounds__(256) void k_prep_x16(PrepX16 a) {
-  const int n = blockIdx.y;
-  const int unit = blockIdx.x * 256 + threadIdx.x;
-  const int OT = a.O >> 4;
-  if (unit >= a.nGx * OT * 64) return;
-  const int lane = unit & 63, ct = (unit >> 6) % OT, gx = (unit >> 6) / OT;
-  const int o = 16 * ct + (lane & 15);
-  const float* e = a.E + (size_t)n * a.d;
-  float gmax = -3.0e38f, gsum = 0.f;
-  if (a.wg) {
-    for (int k = 0; k < a.Ktot; ++k) gmax = fmaxf(gmax, a.wg[k]);
-    for (int k = 0; k < a.Ktot; ++k) gsum += expf(a.wg[k] - gmax);
-  }
-  const int nx = a.Ktot * a.C0;
-  const size_t dstride = (size_t)a.Ktot * a.I * a.O;
-  float v[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int kk = 16 * gx + 4 * (lane >> 4) + s;
-    float val = 0.f;
-    if (kk < nx) {
-      const int k = kk / a.C0, c = kk - k * a.C0;
-      const float* wp = a.wpool + ((size_t)k * a.I + c) * a.O + o;
-      float acc = 0.f;
-      for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], wp[dd * dstride], acc);
-      val = a.wg ? acc * (expf(a.wg[k] - gmax) / gsum) : acc;
-    } else if (kk == nx) {
-      float acc = 0.f;
-      for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], a.bpool[(size_t)dd * a.O + o], acc);
-      val = acc;
-    }
-    v[s] = val;
-  }
-  float* dst = a.out + ((size_t)n * (a.nG + a.nGx) * OT * 64 + (size_t)a.nG * OT * 64 + unit) * 4;
-  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 #endif

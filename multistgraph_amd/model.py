@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import graph_prep
-from .ops import HotPath, PathSpec, spec_from_config
+from .ops import HotPath, PathSpec, diagonal_mask, spec_from_config
 
 try:  # inside a LibCity checkout: subclass the real plugin base so isinstance checks hold
     from libcity.model.abstract_traffic_state_model import AbstractTrafficStateModel  # type: ignore
@@ -150,7 +150,8 @@ class MultiATGCN(AbstractTrafficStateModel):
         self.node_vec1 = nn.Parameter(torch.empty(n, rank))
         self.node_vec2 = nn.Parameter(torch.empty(rank, n))
         self.spec: PathSpec = spec_from_config(config, data_feature, n, rank,
-                                               0 if not use_static else len(mats))
+                                               0 if not use_static else len(mats),
+                                               diagonal_mask(self._static_host))
         self.output_dim = self.spec.out_dim
         self.feature_final = self.spec.feat_in
         self.len_ts = self.spec.n_ts

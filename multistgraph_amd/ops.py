@@ -37,6 +37,7 @@ class PathSpec:
     head_begin: Sequence[int] = (0, 24, 48, 72)
     n_ts: int = 4
     ext_src: Sequence[int] = (1,)
+    diag_static_mask: int = 0       # bit s: static support s is a diagonal matrix (folded, never mixed)
 
     @property
     def scale_by_g(self) -> bool:
@@ -59,6 +60,7 @@ class PathSpec:
         d.adp_mode = _lib.ADP_CODES[self.adpadj]
         d.n_static, d.cheb_k, d.scale_by_g = self.n_static, self.cheb_k, int(self.scale_by_g)
         d.n_heads, d.n_ts = len(self.head_begin), self.n_ts
+        d.diag_static_mask = int(self.diag_static_mask)
         for i, v in enumerate(self.head_begin):
             d.head_begin[i] = int(v)
         for i, v in enumerate(self.ext_src):
@@ -66,7 +68,22 @@ class PathSpec:
         return d
 
 
-def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_static: int) -> PathSpec:
+def diagonal_mask(static_supports) -> int:
+    """Bit s set when static support s (host array / CPU or GPU tensor, (S,N,N)) has no off-diagonal entry.
+    Host-side check made once at model construction; such supports are folded into the weights."""
+    if static_supports is None:
+        return 0
+    st = torch.as_tensor(static_supports).detach().cpu()
+    mask = 0
+    for i in range(st.shape[0]):
+        m = st[i]
+        if torch.count_nonzero(m - torch.diag(torch.diagonal(m))).item() == 0:
+            mask |= 1 << i
+    return mask
+
+
+def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_static: int,
+                     diag_static_mask: int = 0) -> PathSpec:
     """Derive the path description from the reference's config / data_feature keys
     (MultiATGCN.py:224-235, 264-265, 310-332; head windows :371-393)."""
     out_window = config.get("output_window", 1)
@@ -105,7 +122,7 @@ def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_stat
         embed_dim=1 if node_specific_off else config.get("embed_dim_node", 10), adj_rank=adj_rank,
         adpadj=config.get("adpadj", "bidirection"), adjtype=config.get("adjtype", "od"),
         cheb_k=config.get("cheb_order", 2), n_static=n_static, head_begin=tuple(heads),
-        n_ts=int((lp + lt + lc) / 24), ext_src=tuple(ext))
+        n_ts=int((lp + lt + lc) / 24), ext_src=tuple(ext), diag_static_mask=diag_static_mask)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -137,6 +154,7 @@ class HotPath:
         _lib.check(self.lib.matgcn_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_workspace_bytes")
         self.workspace = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
         self.params = _lib.Params()
+        self._static = None
         self._keep: List[torch.Tensor] = []
         self._prepared_ok = False
 
@@ -167,6 +185,7 @@ class HotPath:
         if s.n_static > 0:
             st = _check_tensor(static_supports, "static_supports", (s.n_static, n, n))
             keep.append(st)
+            self._static = st
             p.static_supports = st.data_ptr()
         else:
             p.static_supports = None
@@ -276,11 +295,28 @@ class HotPath:
         return out
 
     def supports(self) -> torch.Tensor:
-        """(Ks, N, N) un-transposed view of the support stack built by matgcn_prepare (tests)."""
+        """(K-1, N, N) non-identity supports in the reference's stack order (tests): the dense slots come from
+        the stack built by matgcn_prepare, the folded (diagonal) ones are re-expanded from their diagonals."""
         self._need_prepared()
         lay = (C.c_int64 * 4)()
         _lib.check(self.lib.matgcn_supports_layout(C.byref(self.dims), C.byref(lay)), "matgcn_supports_layout")
         off, ld, npad, ks = (int(v) for v in lay)
-        n = self.spec.nodes
-        st = self.prepared[off:off + npad * ld].view(npad, ld)
-        return torch.stack([st[:n, k * npad:k * npad + n].t() for k in range(ks)], 0).contiguous()
+        s, n = self.spec, self.spec.nodes
+        st = self.prepared[off:off + npad * ld].view(npad, ld) if ks > 0 else None
+        per = s.cheb_k - 1
+        adp = 0 if s.adpadj == "none" else 1
+        out, kd = [], 0
+        for f in range(s.n_first):
+            diag = f >= adp and (s.diag_static_mask >> (f - adp)) & 1
+            if diag:
+                dvec = torch.diagonal(self._static[f - adp]).double()
+                t0, t1 = torch.ones_like(dvec), dvec
+                for j in range(per):
+                    out.append(torch.diag(t1).float())
+                    t0, t1 = t1, 2 * dvec * t1 - t0
+            else:
+                for j in range(per):
+                    out.append(st[:n, kd * npad:kd * npad + n].t())
+                    kd += 1
+        assert kd == ks
+        return torch.stack([o.to(self.device) for o in out], 0).contiguous()

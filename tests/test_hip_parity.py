@@ -16,12 +16,16 @@ STAGE_TOL = 2e-5
 E2E_TOL = 1e-4
 
 
-def _path(c, lib_built):
-    from multistgraph_amd.ops import HotPath, spec_from_config
+def _path(c, lib_built, fold=True):
+    """fold=True is the product configuration: static supports that are diagonal matrices (the similarity
+    Laplacian without static features, the identity mode) are folded into the weights; fold=False mixes
+    them as dense matrices like any other support."""
+    from multistgraph_amd.ops import HotPath, diagonal_mask, spec_from_config
     dev = torch.device("cuda:0")
     use_static = c.adpadj == "none" or c.adjtype == "multi"
     st = torch.from_numpy(c.gold["static_supports"]).to(dev) if use_static else None
-    spec = spec_from_config(c.config(), c.data_feature, c.n, min(c.n, 20), st.shape[0] if use_static else 0)
+    spec = spec_from_config(c.config(), c.data_feature, c.n, min(c.n, 20), st.shape[0] if use_static else 0,
+                            diagonal_mask(st) if fold else 0)
     hp = HotPath(spec, c.b, dev)
     hp.bind({k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}, st)
     return hp, dev
@@ -65,10 +69,11 @@ def test_agcn_gate(name, lib_built):
     assert max_norm_err(got, c.gold["agcn_gate_l0"]) <= STAGE_TOL
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("name", TINY)
-def test_atgru_cells(name, lib_built):
+def test_atgru_cells(name, fold, lib_built):
     c = Case(name)
-    hp, dev = _path(c, lib_built)
+    hp, dev = _path(c, lib_built, fold)
     x, h, x1 = (torch.from_numpy(c.gold[k]).to(dev) for k in ("stage_x", "stage_h", "stage_x1"))
     assert max_norm_err(hp.atgru_cell(0, x, h).cpu().numpy(), c.gold["cell_l0"]) <= STAGE_TOL
     assert max_norm_err(hp.atgru_cell(1, x1, h).cpu().numpy(), c.gold["cell_l1"]) <= STAGE_TOL
@@ -79,6 +84,7 @@ def test_atgru_cells(name, lib_built):
 def test_encoder_and_head(name, lib_built):
     c = Case(name)
     hp, dev = _path(c, lib_built)
+    assert hp.lib.matgcn_set_wavefront(1) in (0, 1)
     seq, fin = hp.encoder(torch.from_numpy(c.gold["x0"]).to(dev))
     assert max_norm_err(seq.cpu().numpy(), c.gold["enc_seq"]) <= E2E_TOL
     assert max_norm_err(fin.cpu().numpy(), c.gold["enc_finals"]) <= E2E_TOL
@@ -86,10 +92,11 @@ def test_encoder_and_head(name, lib_built):
     assert max_norm_err(out, c.gold["pred"]) <= STAGE_TOL
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("name", TINY + FULL)
-def test_forward(name, lib_built):
+def test_forward(name, fold, lib_built):
     c = Case(name)
-    hp, dev = _path(c, lib_built)
+    hp, dev = _path(c, lib_built, fold)
     got = hp.forward(torch.from_numpy(c.x).to(dev)).cpu().numpy()
     assert got.shape == c.gold["pred"].shape
     assert max_norm_err(got, c.gold["pred"]) <= E2E_TOL
@@ -139,3 +146,16 @@ def test_linearity_of_graph_mix(lib_built):
     lhs = hp.agcn_gate(0, xa, ha) + hp.agcn_gate(0, xb, hb) - z
     rhs = hp.agcn_gate(0, xa + xb, ha + hb)
     assert max_norm_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= 1e-5
+
+
+def test_wavefront_and_serial_schedules_agree_bitwise(lib_built):
+    # the layer wavefront only reorders independent launches: results must be identical to the serial schedule
+    c = Case("dc237_out12")
+    hp, dev = _path(c, lib_built)
+    x = torch.from_numpy(c.x).to(dev)
+    prev = hp.lib.matgcn_set_wavefront(1)
+    a = hp.forward(x).cpu().numpy()
+    hp.lib.matgcn_set_wavefront(0)
+    b = hp.forward(x).cpu().numpy()
+    hp.lib.matgcn_set_wavefront(prev)
+    assert np.array_equal(a, b)
