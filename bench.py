@@ -107,7 +107,7 @@ def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     with torch.no_grad():
         model.predict(batch)            # settle clocks / caches in this mode
     torch.cuda.synchronize()
-    _lib.check(lib.matgcn_profile_enable(63, cap), "matgcn_profile_enable")
+    _lib.check(lib.matgcn_profile_enable(127, cap), "matgcn_profile_enable")
     with torch.no_grad():
         for _ in range(forwards):
             model.predict(batch)
@@ -207,26 +207,7 @@ def main():
 
         serial = in_situ_kernel_times(model, batch, wavefront=False, forwards=2)
         conc = in_situ_kernel_times(model, batch, wavefront=True, forwards=1)
-        # In serial (layer-major) order the launches of one forward are: [fold0] + 48 step launches of layer 0,
-        # then per chunk of layer 1 one x-part launch followed by that chunk's step launches.
-        def split_steps(mix, forwards):
-            per = len(mix) // forwards
-            steps = []
-            for f in range(forwards):
-                one = mix[f * per:(f + 1) * per]
-                idx = 1                                   # skip the layer-0 fold launch
-                steps += one[idx:idx + 48]
-                idx += 48
-                t = 0
-                while t < 24 and idx < len(one):
-                    nt = 1 if t < 2 else (2 if t < 4 else 4)
-                    nt = min(nt, 24 - t)
-                    idx += 1                              # x-part chunk launch
-                    steps += one[idx:idx + 2 * nt]
-                    idx += 2 * nt
-                    t += nt
-            return steps
-        step_mix = split_steps(serial.get("k_mix", []), 2)
+        step_mix = serial.get("k_mix", [])       # k_mix<1>: the 96 per-step launches of each forward
         mix_ms = statistics.mean(step_mix) if step_mix else float("nan")
         achieved = mix_flops / (mix_ms * 1e-3) / 1e12
         conc_mix = conc.get("k_mix", [])
@@ -245,7 +226,7 @@ def main():
                         flops_per_launch=mix_flops,
                         measured="HIP events around each launch, wavefront off (kernel alone on the chip)",
                         in_wavefront=dict(avg_launch_ms=conc_ms, launches=len(conc_mix),
-                                          note="all k_mix launches of one forward of the timed configuration; "
+                                          note="the per-step k_mix<1> launches of one forward of the timed configuration; "
                                                "a launch shares the chip with the other layer's chain"),
                         serial_kernel_ms_per_forward={k: round(sum(v) / 2, 4) for k, v in serial.items()},
                         dense_supports_mixed=ks, supports_folded_into_weights=n_diag * (spec.cheb_k - 1),

@@ -174,8 +174,11 @@ int matgcn_set_wavefront(int enabled);
  * and selects which kernels are bracketed (bit mask of MATGCN_PROF_*); while enabled every selected
  * launch records an event pair until max_launches is reached.  collect() synchronises the recorded
  * events and writes per-launch milliseconds and kernel kinds; disable() destroys the events. */
-enum { MATGCN_PROF_MIX = 1, MATGCN_PROF_GATE = 2, MATGCN_PROF_UPDATE = 4, MATGCN_PROF_RES = 8,
-       MATGCN_PROF_PX = 16, MATGCN_PROF_HEAD = 32, MATGCN_PROF_ALL = 63 };
+enum { MATGCN_PROF_MIX = 1,      /* k_mix<1>: the recurrent step's graph mix (the roofline kernel) */
+       MATGCN_PROF_GATE = 2, MATGCN_PROF_UPDATE = 4, MATGCN_PROF_RES = 8, MATGCN_PROF_PX = 16,
+       MATGCN_PROF_HEAD = 32,
+       MATGCN_PROF_MIX_PRE = 64, /* k_mix<0>: pre-pass mixes (layer-0 fold, x-part chunks) */
+       MATGCN_PROF_ALL = 127 };
 int matgcn_profile_enable(int kind_mask, int max_launches);
 int matgcn_profile_collect(float* ms, int* kinds, int capacity, int* count);
 int matgcn_profile_disable(void);

@@ -79,7 +79,7 @@ _SIGNATURES = {
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "matgcn_profile_disable": (C.c_int, []),
 }
-PROF_KINDS = {1: "k_mix", 2: "k_gate", 4: "k_update", 8: "k_res_gru", 16: "k_px", 32: "k_head"}
+PROF_KINDS = {1: "k_mix", 2: "k_gate", 4: "k_update", 8: "k_res_gru", 16: "k_px", 32: "k_head", 64: "k_mix_pre"}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None

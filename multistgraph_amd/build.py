@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmatgcn.so")
 SOURCES = ["matgcn_capi.hip"]
-DEPS = ["matgcn_capi.hip", "matgcn_kernels.hip", "matgcn_internal.h", os.path.join("..", "..", "include", "matgcn.h")]
+DEPS = ["matgcn_capi.hip", "matgcn_kernels.hip", "matgcn_node16.hip", "matgcn_internal.h",
+        os.path.join("..", "..", "include", "matgcn.h")]
 
 
 def _hipcc() -> str:

@@ -225,22 +225,23 @@ int wavefront_ready() {
 
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
-               float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s) {
+               float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s, bool stepRole = false) {
   if (Ks <= 0 || rowsM <= 0) return MATGCN_OK;   // every support folded away: nothing to mix
   MixArgs a;
   a.St = St; a.ldS = P.Mp; a.X = X; a.xTileStride = xTileStride; a.ldX = ldX;
   a.out = out; a.sN = sN; a.sK = sK; a.sT = sT;
   a.Np = P.Np; a.N = P.N; a.Ks = Ks; a.nK = P.Np / 16; a.nColTiles = nColTiles;
   a.nRowTiles = (int)(rup(rowsM, 64) / 64);
-  ProfScope prof(MATGCN_PROF_MIX, s);
-  hipLaunchKernelGGL(k_mix, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
+  ProfScope prof(stepRole ? MATGCN_PROF_MIX : MATGCN_PROF_MIX_PRE, s);
+  if (stepRole) hipLaunchKernelGGL(k_mix<1>, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_mix<0>, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
   return launch_ok();
 }
 
 // mix of `rows` contiguous [Np][64] slabs into the node-major buffer G [N][rows][Ks][64]
-int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s) {
+int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s, bool stepRole = false) {
   return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, (long)rows * P.Ks * H, H, (long)P.Ks * H, P.Ks,
-                    P.Ks * P.Np, s);
+                    P.Ks * P.Np, s, stepRole);
 }
 
 struct Ctx {
@@ -323,7 +324,7 @@ int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node1
   float* ZHx = c.ws + P.oZHx[l];
   float* G = c.ws + P.oG[l];
   float* R = c.ws + P.oR[l];
-  RETURN_IF(mix_rows(P, St, Hx, P.B, G, s));
+  RETURN_IF(mix_rows(P, St, Hx, P.B, G, s, true));
   Node16Args a;
   memset(&a, 0, sizeof(a));
   a.s = Hx; a.g = G; a.w = c.prep + P.oWg[l];
@@ -338,7 +339,7 @@ int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node1
   }
   CHECK_LAUNCH();
   if (gateOnly) return MATGCN_OK;
-  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, s));
+  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, s, true));
   a.s = ZHx; a.w = c.prep + P.oWu[l]; a.raw = nullptr; a.zh = nullptr;
   a.h = Hx; a.hout = Hx;
   ProfScope prof(MATGCN_PROF_UPDATE, s);
@@ -660,11 +661,6 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
         // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
         q.out = prep + P.oWx[l]; q.nodeStride = P.wxStride; q.baseOfs = 0;
         q.kind = 2; q.iOfs = 0; q.groups = P.Ktot * H / 8; q.OTdst = 6; q.otOfs = part == 0 ? 0 : 4;
-        if (debug_sync())
-          fprintf(stderr, "[matgcn] kind2: out %p..%p E %p wpool %p..%p diag0 %p wg %p prep %p..%p\n", (void*)q.out,
-                  (void*)(q.out + (size_t)P.N * q.nodeStride), (void*)q.E, (void*)q.wpool,
-                  (void*)(q.wpool + (size_t)P.d * P.KtotOrig * I * O), (void*)map.diagSrc[0], (void*)q.wg, (void*)prep,
-                  (void*)(prep + P.preparedFloats));
         hipLaunchKernelGGL(k_prep_stream<2>, dim3(blocks_for((size_t)q.groups * (O / 32) * 64), nodeGroups), dim3(256), 0,
                            c.s, q);
         CHECK_LAUNCH();

@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // LDS (register-prefetched double buffer, one barrier per step).  A = St (k-major, so the tile is 16 rows of
 // 256 contiguous bytes), B = 64 feature columns of one state row (256-byte lines).  Workgroups that share an
 // XCD (id % 8) sweep the row tiles of one column tile back to back, so St and that X slice stay in its L2.
+// ROLE only names the instantiation (0: pre-passes and Chebyshev products, 1: the recurrent step's mix of h / z*h),
+// so that profilers list the roofline kernel - the per-step launch - on its own line.
+template <int ROLE>
 __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][16 * 64];
   __shared__ __attribute__((aligned(16))) float Bs[2][16 * 64];
