@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 3
+#define MATGCN_ABI_VERSION 4
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -69,6 +69,10 @@ typedef struct matgcn_dims {
   int32_t diag_static_mask; /* bit s set: static support s is a diagonal matrix (host-checked, e.g. the
                            * similarity Laplacian -I without static features, :244-250).  Such supports are
                            * folded into the identity slot of the node-adaptive weights and never mixed. */
+  int32_t gcn_off;      /* 1: ablation without graph convolution - encoder.agru_cells are dense GRU cells, no
+                         * residual cells, no blend (:177-192,205-208); their nn.Linear weights are passed in
+                         * matgcn_params.res_gate / res_update, the AGCN / support fields are ignored */
+  int32_t fnn_off;      /* 1: ablation of the temporal head - end_conv sees the last step only (:342-344,412) */
   int32_t head_begin[MATGCN_MAX_HEADS]; /* first X step of head h (trend head never advances) */
   int32_t ext_src[MATGCN_MAX_EXT];      /* X channel copied into encoder channel out_dim+j */
 } matgcn_dims;
@@ -96,7 +100,7 @@ typedef struct matgcn_params { /* device pointers, names = the reference state_d
   matgcn_agcn_params update[MATGCN_MAX_LAYERS];   /* encoder.agru_cells.l.update (O = H)  */
   matgcn_linear_params res_gate[MATGCN_MAX_LAYERS];   /* encoder.res_cells.l.gate   */
   matgcn_linear_params res_update[MATGCN_MAX_LAYERS]; /* encoder.res_cells.l.update */
-  const float* end_conv_weight; /* (out_channels, T, 1, H) */
+  const float* end_conv_weight; /* (out_channels, T, 1, H); (out_channels, 1, 1, H) with fnn_off */
   const float* end_conv_bias;   /* (out_channels) */
 } matgcn_params;
 

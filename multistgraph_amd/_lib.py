@@ -29,7 +29,7 @@ class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "nodes", "in_steps", "x_steps", "x_feat", "out_channels", "out_dim", "start_dim",
         "hidden", "layers", "feat_in", "embed_dim", "adj_rank", "adp_mode", "n_static", "cheb_k",
-        "scale_by_g", "n_heads", "n_ts", "diag_static_mask")] + [
+        "scale_by_g", "n_heads", "n_ts", "diag_static_mask", "gcn_off", "fnn_off")] + [
         ("head_begin", C.c_int32 * MAX_HEADS),
         ("ext_src", C.c_int32 * MAX_EXT),
     ]
@@ -99,8 +99,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 3:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 3" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 4:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 4" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

@@ -29,6 +29,7 @@ inline long rup(long v, long m) { return (v + m - 1) / m * m; }
 struct Plan {
   int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od, Tc;   // Ks/Ktot: DENSE slots (+ identity)
   int per, KtotOrig, nDenseFirst;
+  int gcnOff, headT;          // ablations: dense GRU cells instead of graph cells; head over the last step only
   int denseFirst[4];          // first-order supports that are mixed (index into [adaptive?, statics...])
   int diagFirst[4], nDiagFirst;
   int nc0, nc0p;              // layer-0 plain-matrix columns (B*T*C0) and padded to 64
@@ -74,8 +75,10 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->Np = (int)rup(P->N, 16);
   P->NpC = (int)rup(P->N, 64);
   const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
+  P->gcnOff = D->gcn_off ? 1 : 0;
+  P->headT = D->fnn_off ? 1 : P->T;
   P->nFirst = adp + D->n_static;
-  if (P->nFirst < 1) return MATGCN_ERR_BAD_ARG;
+  if (P->nFirst < 1 && !P->gcnOff) return MATGCN_ERR_BAD_ARG;
   P->per = D->cheb_k - 1;
   P->KtotOrig = 1 + P->nFirst * P->per;
   if (P->KtotOrig > MATGCN_MAX_STACK) return MATGCN_ERR_UNSUPPORTED;
@@ -86,6 +89,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     else P->denseFirst[P->nDenseFirst++] = f;
   }
   P->Ks = P->nDenseFirst * P->per;
+  if (P->gcnOff) { P->Ks = 0; P->nDenseFirst = 0; P->nDiagFirst = 0; }
   P->Ktot = P->Ks + 1;
   P->Mp = (int)rup((long)P->Ks * P->Np, 64);
   P->Kx = (int)rup((long)P->Ktot * P->C0 + 1, 16);   // folded x rows of layer 0 (+ bias row), whole k-groups
@@ -102,10 +106,10 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->Cl[l] = (l == 0) ? P->C0 : H;
     P->Cpad[l] = (int)rup(P->Cl[l], 16);
     P->nGx[l] = (l == 0) ? P->Kx / 16 : 0;
-    const long kt = (long)P->Ktot * H + 16L * P->nGx[l];
+    const long kt = P->gcnOff ? 0 : (long)P->Ktot * H + 16L * P->nGx[l];
     P->oWg[l] = take((long)P->N * kt * 128);
     P->oWu[l] = take((long)P->N * kt * 64);
-    if (l > 0) {
+    if (l > 0 && !P->gcnOff) {
       P->wxStride = (long)P->Ktot * H * 192;
       P->oWx[l] = take((long)P->N * P->wxStride);
       P->oBx[l] = take((long)P->N * 192);
@@ -113,7 +117,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oRg[l] = take((long)(P->Cpad[l] + H) * 128);
     P->oRu[l] = take((long)(P->Cpad[l] + H) * 64);
   }
-  P->oHead = take((long)P->T * H * 32 * P->NTc);
+  P->oHead = take((long)P->headT * H * 32 * P->NTc);
   P->preparedFloats = o;
   P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 4 ? P->Ks : 4)) * (int)sizeof(float);
   // workspace
@@ -129,7 +133,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oG[l] = take((long)P->N * P->B * P->Ks * H);
     P->oR[l] = take((long)P->N * P->B * H);
     P->oSeq[l] = take(rowsBT * P->Np * H);
-    if (l > 0) {
+    if (l > 0 && !P->gcnOff) {
       P->oGX[l] = take((long)P->N * P->B * P->Tc * P->Ks * H);
       P->oPX[l] = take((long)P->T * P->N * P->B * 192);
     }
@@ -386,7 +390,7 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
       HIP_OK(hipStreamWaitEvent(W.xpart[l], W.fork, 0));
     }
   }
-  RETURN_IF(fold_x0(c, x0p, P.T, c.s));
+  if (!P.gcnOff) RETURN_IF(fold_x0(c, x0p, P.T, c.s));
   for (int l = 0; l < P.L; ++l) {
     hipStream_t cs = (l == 0 || !multi) ? c.s : W.chain[l];
     hipStream_t xs = multi ? W.xpart[l] : c.s;
@@ -404,6 +408,23 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
     const long stepRows = (long)P.B * P.Np * H;     // one step of a time-major sequence
     int nextChunk = 0;
     for (int t = 0; t < P.T; ++t) {
+      if (P.gcnOff) {
+        // ablation: the layer is a plain GRU cell on (x_t, h) (MultiATGCN.py:187-192,204): one launch per step
+        if (multi && l > 0) HIP_OK(hipStreamWaitEvent(cs, W.step[l - 1][t], 0));
+        Node16Args a;
+        memset(&a, 0, sizeof(a));
+        a.s = c.ws + P.oHx[l]; a.hout = c.ws + P.oHx[l];
+        a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = 0;
+        if (l == 0) fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0, nullptr, seq + t * stepRows, &a);
+        else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
+        {
+          ProfScope prof(MATGCN_PROF_RES, cs);
+          hipLaunchKernelGGL(k_update16<2>, dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, cs, a);
+        }
+        CHECK_LAUNCH();
+        if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
+        continue;
+      }
       if (l > 0 && t == nextChunk) {
         // x-part chunk [t, t+nt) of this layer, as soon as the layer below has produced those steps; the first
         // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
@@ -459,8 +480,10 @@ int fuse_padded(const Ctx& c, const float* X, float* x0p) {
 int head_padded(const Ctx& c, const float* seqp, float* out) {
   const Plan& P = c.P;
   HeadArgs a;
-  a.seq = seqp; a.w = c.prep + P.oHead; a.bias = c.prm->end_conv_bias; a.out = out;
-  a.B = P.B; a.T = P.T; a.N = P.N; a.Np = P.Np; a.CH = P.CH; a.od = P.od; a.NTc = P.NTc;
+  // fnn_off: the head convolves the last step only (MultiATGCN.py:412)
+  a.seq = seqp + (size_t)(P.T - P.headT) * P.B * P.Np * H; a.w = c.prep + P.oHead;
+  a.bias = c.prm->end_conv_bias; a.out = out;
+  a.B = P.B; a.T = P.headT; a.N = P.N; a.Np = P.Np; a.CH = P.CH; a.od = P.od; a.NTc = P.NTc;
   ProfScope prof(MATGCN_PROF_HEAD, c.s);
   hipLaunchKernelGGL(k_head, dim3((unsigned)(P.B * ((P.N + 31) / 32))), dim3(64), 0, c.s, a);
   return launch_ok();
@@ -477,8 +500,11 @@ int make_ctx(Ctx* c, const matgcn_dims* dims, const matgcn_params* params, const
 }
 
 int check_layer_params(const matgcn_dims* D, const matgcn_params* p) {
-  if (!p->node_emb || !p->weights_gru) return MATGCN_ERR_NULL;
+  if (!D->gcn_off && (!p->node_emb || !p->weights_gru)) return MATGCN_ERR_NULL;
   for (int l = 0; l < D->layers; ++l) {
+    if (!p->res_gate[l].weight || !p->res_gate[l].bias || !p->res_update[l].weight || !p->res_update[l].bias)
+      return MATGCN_ERR_NULL;
+    if (D->gcn_off) continue;
     if (!p->gate[l].weights_pool || !p->gate[l].bias_pool || !p->update[l].weights_pool || !p->update[l].bias_pool)
       return MATGCN_ERR_NULL;
     if (D->scale_by_g && (!p->gate[l].weights_g || !p->update[l].weights_g)) return MATGCN_ERR_NULL;
@@ -493,6 +519,7 @@ int check_layer_params(const matgcn_dims* D, const matgcn_params* p) {
 int stage_single_step(const Ctx& c, int layer, const float* x, const float* h, bool xpart, float** xin_out) {
   const Plan& P = c.P;
   if (layer < 0 || layer >= P.L) return MATGCN_ERR_BAD_ARG;
+  if (P.gcnOff && xpart) return MATGCN_ERR_UNSUPPORTED;   // no graph cell exists in this ablation
   RETURN_IF(node_kernels_ready(P.nodeLds));
   // layer 0 stages into x0p, deeper layers into step 0 of the sequence of the layer below
   float* xin = (layer == 0) ? c.ws + P.oX0p : c.ws + P.oSeq[layer - 1];
@@ -568,8 +595,10 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   const Plan& P = c.P;
   if (prepared_bytes < (size_t)P.preparedFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   RETURN_IF(check_layer_params(dims, params));
-  if (dims->adp_mode == MATGCN_ADP_UNI && (!params->node_vec1 || !params->node_vec2)) return MATGCN_ERR_NULL;
-  if (dims->n_static > 0 && !params->static_supports) return MATGCN_ERR_NULL;   // also the diagonal ones
+  if (!P.gcnOff) {
+    if (dims->adp_mode == MATGCN_ADP_UNI && (!params->node_vec1 || !params->node_vec2)) return MATGCN_ERR_NULL;
+    if (dims->n_static > 0 && !params->static_supports) return MATGCN_ERR_NULL;   // also the diagonal ones
+  }
   if (!params->end_conv_weight || !params->end_conv_bias) return MATGCN_ERR_NULL;
   float* prep = (float*)prepared;
   float* St = prep + P.oSt;
@@ -636,7 +665,7 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   const unsigned nodeGroups = (unsigned)((P.N + PREP_NB - 1) / PREP_NB);
   for (int l = 0; l < P.L; ++l) {
     const int I = P.Cl[l] + H;
-    for (int part = 0; part < 2; ++part) {  // 0 gate (O=128), 1 update (O=64)
+    for (int part = 0; part < 2 && !P.gcnOff; ++part) {  // 0 gate (O=128), 1 update (O=64)
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
       const int nG = 4 * P.Ktot;
@@ -677,8 +706,8 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
                        params->res_update[l].weight, I, 64, P.Cl[l], P.Cpad[l], nG1, prep + P.oRu[l]);
     CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.T * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
-                     params->end_conv_weight, P.T * H, P.CH, 0, 0, P.T * H, P.NTc, prep + P.oHead);
+  hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.headT * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
+                     params->end_conv_weight, P.headT * H, P.CH, 0, 0, P.headT * H, P.NTc, prep + P.oHead);
   return launch_ok();
 }
 

@@ -87,15 +87,18 @@ class _DenseCellParams(nn.Module):
 class _EncoderParams(nn.Module):
     """ATGRUEncoder parameter tree (MultiATGCN.py:156-186)."""
 
-    def __init__(self, layers, in_steps, feat_in, hidden, k_total, embed_dim):
+    def __init__(self, layers, in_steps, feat_in, hidden, k_total, embed_dim, gcn_off=False):
         super().__init__()
         self.agru_cells = nn.ModuleList()
         self.res_cells = nn.ModuleList()
         self.weights_gru = nn.Parameter(torch.empty(layers, in_steps))
         for l in range(layers):
             cin = feat_in if l == 0 else hidden
-            self.agru_cells.append(_GraphCellParams(cin, hidden, k_total, embed_dim))
-            self.res_cells.append(_DenseCellParams(cin, hidden))
+            if gcn_off:   # dense GRU cells take the place of the graph cells, no residual cells (:187-192)
+                self.agru_cells.append(_DenseCellParams(cin, hidden))
+            else:
+                self.agru_cells.append(_GraphCellParams(cin, hidden, k_total, embed_dim))
+                self.res_cells.append(_DenseCellParams(cin, hidden))
 
 
 class MultiATGCN(AbstractTrafficStateModel):
@@ -129,8 +132,6 @@ class MultiATGCN(AbstractTrafficStateModel):
         if data_feature.get("static", None) is not None:
             raise NotImplementedError("add_static (PCA initial state, :286-296,:406-409) is not built yet: "
                                       "pass static=None (DESIGN.md, out of scope this round)")
-        if self.gcn_off or self.fnn_off:
-            raise NotImplementedError("gcn_off / fnn_off ablation switches are not built yet (DESIGN.md)")
         if self.input_window != 24:
             raise ValueError("the reference fuses 24-step heads (:373-393): input_window must be 24")
         if self.node_specific_off:
@@ -159,9 +160,9 @@ class MultiATGCN(AbstractTrafficStateModel):
             [nn.Parameter(torch.empty(1, 24, n, self.output_dim)) for _ in range(self.len_ts)])
         self.weight_tsg = nn.Parameter(torch.empty(self.len_ts))
         self.encoder = _EncoderParams(self.num_layers, self.input_window, self.feature_final, self.hidden_dim,
-                                      self.spec.k_total, self.embed_dim_node)
-        self.end_conv = nn.Conv2d(self.input_window, self.output_window * self.output_dim,
-                                  kernel_size=(1, self.hidden_dim), bias=True)
+                                      self.spec.k_total, self.embed_dim_node, self.gcn_off)
+        self.end_conv = nn.Conv2d(1 if self.fnn_off else self.input_window, self.output_window * self.output_dim,
+                                  kernel_size=(1, self.hidden_dim), bias=True)   # (:340-344)
         self._logger = getLogger()
         self._scaler = data_feature.get("scaler")
         self._init_parameters()

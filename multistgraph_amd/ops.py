@@ -38,6 +38,8 @@ class PathSpec:
     n_ts: int = 4
     ext_src: Sequence[int] = (1,)
     diag_static_mask: int = 0       # bit s: static support s is a diagonal matrix (folded, never mixed)
+    gcn_off: bool = False           # ablation: dense GRU cells instead of graph cells (MultiATGCN.py:177-192)
+    fnn_off: bool = False           # ablation: head over the last step only (:342-344,412)
 
     @property
     def scale_by_g(self) -> bool:
@@ -61,6 +63,7 @@ class PathSpec:
         d.n_static, d.cheb_k, d.scale_by_g = self.n_static, self.cheb_k, int(self.scale_by_g)
         d.n_heads, d.n_ts = len(self.head_begin), self.n_ts
         d.diag_static_mask = int(self.diag_static_mask)
+        d.gcn_off, d.fnn_off = int(self.gcn_off), int(self.fnn_off)
         for i, v in enumerate(self.head_begin):
             d.head_begin[i] = int(v)
         for i, v in enumerate(self.ext_src):
@@ -122,7 +125,8 @@ def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_stat
         embed_dim=1 if node_specific_off else config.get("embed_dim_node", 10), adj_rank=adj_rank,
         adpadj=config.get("adpadj", "bidirection"), adjtype=config.get("adjtype", "od"),
         cheb_k=config.get("cheb_order", 2), n_static=n_static, head_begin=tuple(heads),
-        n_ts=int((lp + lt + lc) / 24), ext_src=tuple(ext), diag_static_mask=diag_static_mask)
+        n_ts=int((lp + lt + lc) / 24), ext_src=tuple(ext), diag_static_mask=diag_static_mask,
+        gcn_off=bool(config.get("gcn_off", False)), fnn_off=bool(config.get("fnn_off", False)))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -196,16 +200,20 @@ class HotPath:
         kt = s.k_total
         for l in range(s.layers):
             cin = (s.feat_in if l == 0 else h) + h
-            for nm, o, dst in (("gate", 2 * h, p.gate), ("update", h, p.update)):
-                pre = "encoder.agru_cells.%d.%s." % (l, nm)
-                dst[l].weights_g = dev(pre + "weights_g", (kt, 1, 1))
-                dst[l].weights_pool = dev(pre + "weights_pool", (d, kt, cin, o))
-                dst[l].bias_pool = dev(pre + "bias_pool", (d, o))
+            if not s.gcn_off:
+                for nm, o, dst in (("gate", 2 * h, p.gate), ("update", h, p.update)):
+                    pre = "encoder.agru_cells.%d.%s." % (l, nm)
+                    dst[l].weights_g = dev(pre + "weights_g", (kt, 1, 1))
+                    dst[l].weights_pool = dev(pre + "weights_pool", (d, kt, cin, o))
+                    dst[l].bias_pool = dev(pre + "bias_pool", (d, o))
+            # gcn_off: encoder.agru_cells hold the dense GRU cells; they travel in the res_* fields
+            cells = "encoder.agru_cells" if s.gcn_off else "encoder.res_cells"
             for nm, o, dst in (("gate", 2 * h, p.res_gate), ("update", h, p.res_update)):
-                pre = "encoder.res_cells.%d.%s." % (l, nm)
+                pre = "%s.%d.%s." % (cells, l, nm)
                 dst[l].weight = dev(pre + "weight", (o, cin))
                 dst[l].bias = dev(pre + "bias", (o,))
-        p.end_conv_weight = dev("end_conv.weight", (s.out_window * s.out_dim, s.in_steps, 1, h))
+        p.end_conv_weight = dev("end_conv.weight",
+                                (s.out_window * s.out_dim, 1 if s.fnn_off else s.in_steps, 1, h))
         p.end_conv_bias = dev("end_conv.bias", (s.out_window * s.out_dim,))
         self._keep = keep
         self._prepared_ok = False

@@ -133,7 +133,7 @@ def _scale_for(name: str, shape) -> float:
         return (30.0 if k > 3 else 6.0) / np.sqrt(d * k * i * 0.5)
     if name.endswith("bias_pool"):
         return 0.15
-    if name.startswith("encoder.res_cells") and name.endswith("weight"):
+    if (name.startswith("encoder.res_cells") or name.startswith("encoder.agru_cells")) and name.endswith(".weight"):
         return 1.6 / np.sqrt(shape[1])
     if name.startswith("end_conv") and name.endswith("weight"):
         return 1.5 / np.sqrt(shape[1] * shape[3])
@@ -160,10 +160,13 @@ def closed_form_state(shapes: dict, seed: int = 0) -> dict:
 def param_shapes(n: int, *, out_steps: int, hidden: int = 64, layers: int = 2,
                  embed_dim_node: int = 20, embed_dim_adj: int = 20, feat_in: int = 2,
                  out_dim: int = 1, k_total: int = 5, len_ts: int = 4, in_steps: int = 24,
-                 adj_rank: int | None = None) -> dict:
-    """The checkpoint ABI of the reference model (MultiATGCN.py:285-344)."""
+                 adj_rank: int | None = None, gcn_off: bool = False, fnn_off: bool = False,
+                 node_specific_off: bool = False) -> dict:
+    """The checkpoint ABI of the reference model (MultiATGCN.py:285-344), including the
+    ablation switches: gcn_off puts dense GRU cells into encoder.agru_cells and drops res_cells (:177-192),
+    fnn_off convolves the last step only (:342-344), node_specific_off shrinks the node embedding to 1 (:350-354)."""
     r = min(n, embed_dim_adj) if adj_rank is None else adj_rank
-    d = embed_dim_node
+    d = 1 if node_specific_off else embed_dim_node
     shapes = {
         "node_emb": (n, d),
         "node_vec1": (n, r),
@@ -177,16 +180,20 @@ def param_shapes(n: int, *, out_steps: int, hidden: int = 64, layers: int = 2,
         cin = (feat_in if l == 0 else hidden) + hidden
         for nm, o in (("gate", 2 * hidden), ("update", hidden)):
             p = "encoder.agru_cells.%d.%s." % (l, nm)
-            shapes[p + "weights_g"] = (k_total, 1, 1)
-            shapes[p + "weights_pool"] = (d, k_total, cin, o)
-            shapes[p + "bias_pool"] = (d, o)
-    for l in range(layers):
+            if gcn_off:
+                shapes[p + "weight"] = (o, cin)
+                shapes[p + "bias"] = (o,)
+            else:
+                shapes[p + "weights_g"] = (k_total, 1, 1)
+                shapes[p + "weights_pool"] = (d, k_total, cin, o)
+                shapes[p + "bias_pool"] = (d, o)
+    for l in range(layers if not gcn_off else 0):
         cin = (feat_in if l == 0 else hidden) + hidden
         for nm, o in (("gate", 2 * hidden), ("update", hidden)):
             p = "encoder.res_cells.%d.%s." % (l, nm)
             shapes[p + "weight"] = (o, cin)
             shapes[p + "bias"] = (o,)
-    shapes["end_conv.weight"] = (out_steps * out_dim, in_steps, 1, hidden)
+    shapes["end_conv.weight"] = (out_steps * out_dim, 1 if fnn_off else in_steps, 1, hidden)
     shapes["end_conv.bias"] = (out_steps * out_dim,)
     return shapes
 

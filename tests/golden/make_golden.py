@@ -38,6 +38,7 @@ def build_reference(case):
                adjtype=case["adjtype"], adpadj=case["adpadj"], cheb_order=case["cheb"],
                embed_dim_node=20, embed_dim_adj=20, rnn_units=64, num_layers=2,
                device=torch.device("cpu"), batch_size=case["batch"])
+    cfg.update(case.get("flags", {}))        # ablation switches: gcn_off / fnn_off / node_specific_off
     torch.manual_seed(0)
     model = REF.MultiATGCN(cfg, df).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -142,6 +143,14 @@ CASES.append(dict(name="bm403_out24", nodes=403, batch=4, out=24, feat=2, adjtyp
                   adpadj="unidirection", cheb=2, seed=0, city="BM"))
 CASES.append(dict(name="bm403_out24_bi", nodes=403, batch=2, out=24, feat=2, adjtype="multi",
                   adpadj="bidirection", cheb=2, seed=100, city="BM"))
+
+
+# ablation switches of the reference (run_model_parameter.py:6-15), final outputs only
+for nm, flags in (("gcnoff", {"gcn_off": True}), ("fnnoff", {"fnn_off": True}),
+                  ("nodeoff", {"node_specific_off": True}),
+                  ("gcnfnnoff", {"gcn_off": True, "fnn_off": True})):
+    CASES.append(dict(name="abl_%s" % nm, nodes=21, batch=3, out=6, feat=2, adjtype="multi",
+                      adpadj="unidirection", cheb=2, seed=10, flags=flags))
 
 
 def main():

@@ -23,9 +23,11 @@ class Case:
         m = self.meta
         self.n, self.b, self.out, self.feat = m["nodes"], m["batch"], m["out"], m["feat"]
         self.adjtype, self.adpadj, self.cheb, self.seed = m["adjtype"], m["adpadj"], m["cheb"], m["seed"]
+        self.flags = dict(m.get("flags", {}))
         self.k_total = syn.k_total_for(self.adjtype, self.adpadj, self.cheb)
         self.data_feature = syn.make_data_feature(self.n, self.seed, m.get("city", "DC"), ext_dim=self.feat - 1)
-        self.shapes = syn.param_shapes(self.n, out_steps=self.out, feat_in=self.feat, k_total=self.k_total)
+        self.shapes = syn.param_shapes(self.n, out_steps=self.out, feat_in=self.feat, k_total=self.k_total,
+                                       **self.flags)
         self.state = syn.closed_form_state(self.shapes, self.seed)
         self.x, self.y = syn.make_batch_arrays(self.b, self.n, self.out, self.seed, feat=self.feat)
 
@@ -33,13 +35,13 @@ class Case:
         return dict(input_window=24, output_window=self.out, add_time_in_day=True, add_day_in_week=False,
                     load_dynamic=self.feat > 2, adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb,
                     embed_dim_node=20, embed_dim_adj=20, rnn_units=64, num_layers=2, device=torch.device(device),
-                    batch_size=self.b)
+                    batch_size=self.b, **self.flags)
 
     def oracle_cfg(self):
         return dict(adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb, num_layers=2, rnn_units=64,
                     len_closeness=48, len_period=24, len_trend=24, output_window=self.out, input_window=24,
                     add_time_in_day=True, add_day_in_week=False, load_dynamic=self.feat > 2, start_dim=0,
-                    end_dim=1)
+                    end_dim=1, **self.flags)
 
     def checksums_ok(self):
         xs = float(self.x.astype(np.float64).sum())

@@ -33,7 +33,7 @@ def test_graph_prep_unsorted_geo_ids():
 
 
 @pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_od_non_c3", "tiny_multi_non_c3", "tiny_multi_uni_dyn7",
-                                  "dc237_out12"])
+                                  "dc237_out12", "abl_gcnoff", "abl_fnnoff", "abl_nodeoff", "abl_gcnfnnoff"])
 def test_parameter_tree_is_the_checkpoint_abi(name):
     from multistgraph_amd.model import MultiATGCN
     c = Case(name)
@@ -45,8 +45,11 @@ def test_parameter_tree_is_the_checkpoint_abi(name):
     # the reference init law: xavier for >= 2-D, U(0,1) for 1-D
     m2 = MultiATGCN(c.config(), c.data_feature)
     assert 0.0 <= float(m2.weight_tsg.min()) and float(m2.weight_tsg.max()) <= 1.0
-    bound = (6.0 / (c.n + 20)) ** 0.5
-    assert float(m2.node_emb.abs().max()) <= bound + 1e-6
+    if c.flags.get("node_specific_off"):
+        assert float(m2.node_emb.min()) == 1.0 == float(m2.node_emb.max()) and not m2.node_emb.requires_grad
+    else:
+        bound = (6.0 / (c.n + 20)) ** 0.5
+        assert float(m2.node_emb.abs().max()) <= bound + 1e-6
 
 
 def test_spec_from_config_heads_and_channels():
@@ -68,8 +71,6 @@ def test_unsupported_options_fail_loudly():
     from multistgraph_amd import synthetic as syn
     from multistgraph_amd.model import MultiATGCN
     c = Case("tiny_multi_uni_c2")
-    with pytest.raises(NotImplementedError):
-        MultiATGCN(dict(c.config(), gcn_off=True), c.data_feature)
     df = dict(c.data_feature, static=syn.make_static(c.n, 5, 0))
     with pytest.raises(NotImplementedError):
         MultiATGCN(c.config(), df)
@@ -86,7 +87,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym)
-    assert lib.matgcn_abi_version() == 3
+    assert lib.matgcn_abi_version() == 4
     assert lib.matgcn_error_string(-3) == b"configuration not supported by this build"
 
 
@@ -110,3 +111,16 @@ def test_size_queries_and_argument_checks(lib_built):
     d = spec.dims(0)
     assert lib.matgcn_prepared_bytes(C.byref(d), C.byref(nb)) == -2     # bad arg
     assert lib.matgcn_prepared_bytes(None, C.byref(nb)) == -1           # null
+
+
+def test_diagonal_supports_are_detected_on_the_host():
+    # no static features: the similarity Laplacian is exactly -I (MultiATGCN.py:244-250) -> bit 2 of the mask
+    from multistgraph_amd.model import MultiATGCN
+    from multistgraph_amd.ops import diagonal_mask
+    c = Case("tiny_multi_uni_c2")
+    m = MultiATGCN(c.config(), c.data_feature)
+    assert m.spec.n_static == 3 and m.spec.diag_static_mask == 0b100
+    assert diagonal_mask(torch.stack([torch.eye(4), torch.ones(4, 4), -2 * torch.eye(4)])) == 0b101
+    assert diagonal_mask(None) == 0
+    ci = Case("tiny_identity_non_c2")
+    assert MultiATGCN(ci.config(), ci.data_feature).spec.diag_static_mask == 1
