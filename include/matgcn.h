@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 4
+#define MATGCN_ABI_VERSION 5
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -45,6 +45,7 @@ enum { MATGCN_ADP_NONE = 0, MATGCN_ADP_UNI = 1, MATGCN_ADP_BI = 2 };
 #define MATGCN_MAX_LAYERS 4
 #define MATGCN_MAX_HEADS 8
 #define MATGCN_MAX_EXT 16
+#define MATGCN_MAX_XSTEPS 256 /* x_steps accepted by matgcn_forward_series */
 
 typedef struct matgcn_dims {
   int32_t batch;        /* B */
@@ -132,6 +133,17 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
 int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                    const float* X, float* out, void* workspace, size_t workspace_bytes,
                    void* stream);
+
+/* The same forward fed from the raw series instead of materialised windows (replaces the window build of
+ * MTHDataset._generate_input_data, libcity/data/dataset/dataset_subclass/mth_dataset.py:110-160, and the
+ * per-batch host copy of data/utils.py:68-72 + batch.py:43-57): series (series_steps, N, F) resident on the
+ * device, label_start (B) device int32 - the first target step of each sample -, rel_steps (x_steps) HOST
+ * int32 - offset of every window row relative to its label start (multistgraph_amd/windows.py).
+ * Row s of sample b is series[label_start[b] + rel_steps[s]]; the caller guarantees they are in range. */
+int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                          const float* series, int64_t series_steps, const int32_t* label_start,
+                          const int32_t* rel_steps, float* out, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ---- the pieces (same kernels, exposed for parity tests against the reference's modules) ----
  * temporal-head fusion + channel concat (MultiATGCN.py:365-402): X -> x0 (B, T, N, feat_in) */

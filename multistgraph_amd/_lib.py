@@ -64,6 +64,8 @@ _SIGNATURES = {
     "matgcn_supports_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_int64 * 4)]),
     "matgcn_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_size_t, _P, C.c_size_t, _P]),
     "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_forward_series": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.c_int64, _P,
+                                        C.POINTER(C.c_int32), _P, _P, C.c_size_t, _P]),
     "matgcn_fuse_heads": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.c_size_t, _P]),
     "matgcn_agcn_gate_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
                                        C.c_size_t, _P]),
@@ -99,8 +101,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 4:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 4" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 5:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 5" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

@@ -461,13 +461,17 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
   return MATGCN_OK;
 }
 
-int fuse_padded(const Ctx& c, const float* X, float* x0p) {
+int fuse_padded(const Ctx& c, const float* X, float* x0p, const int32_t* labelStart = nullptr,
+                const int32_t* relSteps = nullptr) {
   const Plan& P = c.P;
   const matgcn_dims* D = c.D;
   RETURN_IF(zero_async(x0p, (long)P.B * P.T * P.Np * P.C0, c.s));
   FuseArgs a;
   memset(&a, 0, sizeof(a));
   a.X = X; a.x0 = x0p; a.tsg = c.prm->weight_tsg;
+  a.labelStart = labelStart;
+  if (labelStart)
+    for (int s2 = 0; s2 < D->x_steps; ++s2) a.rel[s2] = relSteps[s2];
   for (int h = 0; h < D->n_heads; ++h) { a.ts[h] = c.prm->weight_ts[h]; a.headBegin[h] = D->head_begin[h]; }
   for (int j = 0; j < P.C0 - P.od; ++j) a.extSrc[j] = D->ext_src[j];
   a.B = P.B; a.T = P.T; a.N = P.N; a.Np = P.Np; a.C0 = P.C0; a.od = P.od; a.F = D->x_feat;
@@ -722,6 +726,28 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, X, x0p));
+  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+}
+
+int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                          const float* series, int64_t series_steps, const int32_t* label_start,
+                          const int32_t* rel_steps, float* out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!prepared || !series || !label_start || !rel_steps || !out) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
+  for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
+  RETURN_IF(check_layer_params(dims, params));
+  if (dims->x_steps > MATGCN_MAX_XSTEPS) return MATGCN_ERR_UNSUPPORTED;
+  // the host-visible part of the range contract: no window row may start before the series
+  int lo = 0;
+  for (int s2 = 0; s2 < dims->x_steps; ++s2) lo = rel_steps[s2] < lo ? rel_steps[s2] : lo;
+  if (series_steps < 1 || -(int64_t)lo >= series_steps) return MATGCN_ERR_BAD_ARG;
+  const Plan& P = c.P;
+  float* x0p = c.ws + P.oX0p;
+  RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps));
   RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
 }

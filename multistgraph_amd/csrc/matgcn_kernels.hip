@@ -354,19 +354,24 @@ __global__ __launch_bounds__(256) void k_fuse_heads(FuseArgs a) {
   float gmax = -3.0e38f, gsum = 0.f;
   for (int h = 0; h < a.nTs; ++h) gmax = fmaxf(gmax, a.tsg[h]);
   for (int h = 0; h < a.nTs; ++h) gsum += expf(a.tsg[h] - gmax);
+  // row `step` of sample b: a window row, or - series mode - the series row at label start + rel[step]
+  auto xrow = [&](int step) -> const float* {
+    const size_t r = a.labelStart ? (size_t)(a.labelStart[b] + a.rel[step]) : (size_t)b * a.xSteps + step;
+    return a.X + (r * a.N + n) * a.F;
+  };
   float* dst = a.x0 + (((size_t)b * a.T + t) * a.Np + n) * a.C0;
   for (int c = 0; c < a.od; ++c) {
     float acc = 0.f;
     for (int h = 0; h < a.nHeads; ++h) {
       const float g = expf(a.tsg[h] - gmax) / gsum;
-      const float xv = a.X[(((size_t)b * a.xSteps + a.headBegin[h] + t) * a.N + n) * a.F + a.startDim + c];
+      const float xv = xrow(a.headBegin[h] + t)[a.startDim + c];
       const float wv = a.ts[h][((size_t)t * a.N + n) * a.od + c];
       acc += g * xv * wv;
     }
     dst[c] = acc;
   }
   for (int j = 0; j < a.C0 - a.od; ++j)
-    dst[a.od + j] = a.X[(((size_t)b * a.xSteps + t) * a.N + n) * a.F + a.extSrc[j]];
+    dst[a.od + j] = xrow(t)[a.extSrc[j]];
 }
 
 // layer-0 encoder input as a plain matrix for the mix GEMM: X0m[m][(row*C0 + c)] = x0p[row][m][c]

@@ -191,14 +191,16 @@ class MultiATGCN(AbstractTrafficStateModel):
         if not x.is_cuda:
             raise RuntimeError("MultiATGCN.forward runs on the HIP hot path only: batch['X'] is on %s. "
                                "Move the model and the batch to the GPU (config['device'])." % x.device)
-        batch = x.shape[0]
+        return self._path_for_batch(x.shape[0], x.device)
+
+    def _path_for_batch(self, batch: int, device) -> HotPath:
         hp = self._paths.get(batch)
-        if hp is None or hp.device != x.device:
-            hp = HotPath(self.spec, batch, x.device)
+        if hp is None or hp.device != device:
+            hp = HotPath(self.spec, batch, device)
             self._paths[batch] = hp
             self._prepared_key = None
-        if self._static_host is not None and (self._static_dev is None or self._static_dev.device != x.device):
-            self._static_dev = self._static_host.to(x.device).contiguous()
+        if self._static_host is not None and (self._static_dev is None or self._static_dev.device != device):
+            self._static_dev = self._static_host.to(device).contiguous()
         key = (id(hp),) + self._params_key()
         if key != self._prepared_key or not self.cache_prepared:
             hp.bind(self._state(), self._static_dev)
@@ -220,6 +222,20 @@ class MultiATGCN(AbstractTrafficStateModel):
 
     def predict(self, batch):
         return self.forward(batch)
+
+    def predict_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+        """predict() without materialised windows: ``series`` (T, N, F) float32 resident on the GPU, ``label_start``
+        (B) int32 first-target indices; the window rows are gathered on the device (windows.window_offsets gives
+        ``rel_steps``; the default is the reference's 2 x 24 h closeness + 1-week + 4-week heads)."""
+        from . import windows
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("forward only: call under torch.no_grad()")
+        if rel_steps is None:
+            rel_steps = windows.window_offsets(self.input_window)
+        if not series.is_cuda:
+            raise RuntimeError("predict_series needs the series on the GPU (HIP path only)")
+        hp = self._path_for_batch(int(label_start.shape[0]), series.device)
+        return hp.forward_series(series, label_start.to(torch.int32), rel_steps)
 
     def calculate_loss(self, batch):
         """de-scale prediction and label, masked MAE with null value 0 (:422-427)."""

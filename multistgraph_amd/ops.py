@@ -242,6 +242,28 @@ class HotPath:
                                            C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward")
         return out
 
+    def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps) -> torch.Tensor:
+        """Forward fed from the device-resident series (T, N, F): sample b's window rows are gathered by the
+        head-fusion prologue from series[label_start[b] + rel_steps[s]] (multistgraph_amd/windows.py)."""
+        s = self.spec
+        if series.dim() != 3 or tuple(series.shape[1:]) != (s.nodes, s.x_feat):
+            raise _lib.MatgcnError("series has shape %s, expected (T, %d, %d)" % (tuple(series.shape), s.nodes, s.x_feat))
+        series = _check_tensor(series, "series")
+        if not label_start.is_cuda or label_start.dtype != torch.int32 or tuple(label_start.shape) != (self.batch,):
+            raise _lib.MatgcnError("label_start must be a CUDA int32 tensor of shape (%d,)" % self.batch)
+        rel = [int(v) for v in rel_steps]
+        if len(rel) != s.x_steps:
+            raise _lib.MatgcnError("rel_steps has %d entries, x_steps is %d" % (len(rel), s.x_steps))
+        self._need_prepared()
+        out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        rel_c = (C.c_int32 * len(rel))(*rel)
+        _lib.check(self.lib.matgcn_forward_series(
+            C.byref(self.dims), C.byref(self.params), C.c_void_p(self.prepared.data_ptr()),
+            C.c_void_p(series.data_ptr()), C.c_int64(series.shape[0]), C.c_void_p(label_start.contiguous().data_ptr()),
+            rel_c, C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward_series")
+        return out
+
     def fuse_heads(self, x: torch.Tensor) -> torch.Tensor:
         s = self.spec
         x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))

@@ -1,0 +1,54 @@
+"""Multi-temporal-head windows kept on the device.
+
+The reference materialises every sample's input as a (96, N, F) window (``MTHDataset._generate_input_data``,
+reference libcity/data/dataset/dataset_subclass/mth_dataset.py:31-160): closeness = the ``len_closeness``
+blocks of ``input_window`` steps right before the label, period / trend = one block ``interval * 24 h`` before
+the label each, stacked as [closeness oldest -> newest | period | trend] - ~1-2 GB of float64 host arrays that
+are deep-copied per batch and shipped over PCIe (data/utils.py:68-72, batch.py:43-57).
+
+Here the raw series (T, N, F) stays resident in HBM and a batch is just B label-start indices: the head-fusion
+prologue of the hot path gathers the window rows itself (matgcn_forward_series), so no window is ever built.
+``window_offsets`` restates the reference's index arithmetic; it is pinned against the reference's own functions
+by tests/golden/windows_small.npz.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+
+def window_offsets(input_window: int = 24, len_closeness: int = 2, len_period: int = 1, len_trend: int = 1,
+                   interval_period: int = 7, interval_trend: int = 28, points_per_hour: int = 1,
+                   hour_each_day: int = 24) -> np.ndarray:
+    """Offsets (relative to the label start) of the x_steps rows of one sample, in the reference's order
+    (mth_dataset.py:31-60 ``_search_data``, :82-104, :145-158).  Each block is ``input_window`` consecutive rows."""
+    def blocks(count: int, units: float) -> List[int]:
+        starts = [-int(points_per_hour * units * i) for i in range(1, count + 1)]
+        return starts[::-1]                                   # oldest first (:60)
+
+    rel: List[int] = []
+    for start in blocks(len_closeness, input_window / points_per_hour):
+        rel += list(range(start, start + input_window))
+    for start in blocks(len_period, interval_period * hour_each_day):
+        rel += list(range(start, start + input_window))
+    for start in blocks(len_trend, interval_trend * hour_each_day):
+        rel += list(range(start, start + input_window))
+    return np.asarray(rel, dtype=np.int32)
+
+
+def valid_label_starts(series_steps: int, rel: np.ndarray, input_window: int = 24) -> np.ndarray:
+    """Label starts the reference keeps: every block inside the series and ``input_window`` target rows available
+    (mth_dataset.py:48-57, :79-80)."""
+    lo = int(-rel.min())
+    hi = series_steps - input_window
+    return np.arange(lo, hi + 1, dtype=np.int32) if hi >= lo else np.zeros(0, dtype=np.int32)
+
+
+def gather_windows(series: np.ndarray, starts: np.ndarray, rel: np.ndarray, output_window: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Host restatement of ``_generate_input_data`` for the given label starts: (B, x_steps, N, F) sources and
+    (B, output_window, N, F) targets.  Test infrastructure / cross-check only - the product path never builds X."""
+    idx = starts[:, None].astype(np.int64) + rel[None, :].astype(np.int64)
+    x = series[idx]
+    y = series[starts[:, None].astype(np.int64) + np.arange(output_window)[None, :]]
+    return x, y

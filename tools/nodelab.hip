@@ -13,8 +13,9 @@ template <int PATTERN>
 __global__ __launch_bounds__(512) void k_stream(const float* __restrict__ w, float* __restrict__ out, int nG) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4* wp = PATTERN == 0 ? reinterpret_cast<const float4*>(w) + ((size_t)n * nG * 8 + wv) * 64 + lane      // [g][ct] interleaved
-                                  : reinterpret_cast<const float4*>(w) + ((size_t)(n * 8 + wv) * nG) * 64 + lane;   // wave-contiguous
-  const size_t gs = PATTERN == 0 ? 8 * 64 : 64;
+                   : PATTERN == 1 ? reinterpret_cast<const float4*>(w) + ((size_t)(n * 8 + wv) * nG) * 64 + lane     // wave-contiguous
+                   : reinterpret_cast<const float4*>(w) + (size_t)n * (nG * 8 * 64 + (PATTERN == 2 ? 16 : 80)) + wv * 64 + lane;  // padded node stride
+  const size_t gs = PATTERN == 1 ? 64 : 8 * 64;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 r[10];
 #pragma unroll
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < floats; i += 97) h[i] = 0.001f * (i % 1000); CK(hipMemcpy(p, h.data(), floats * 4, hipMemcpyHostToDevice)); return p; };
   float* S = dalloc((size_t)B * Np * 64, 0.1f);
   float* G = dalloc((size_t)N * B * Ks * 64, 0.1f);
-  float* Wg = dalloc((size_t)N * nG * 16 * 128, 0.01f);
+  float* Wg = dalloc((size_t)N * (nG * 16 * 128 + 1024), 0.01f);
   float* Wu = dalloc((size_t)N * nG * 16 * 64, 0.01f);
   float* PX = dalloc((size_t)N * B * 192, 0.1f);
   float* ZH = dalloc((size_t)B * Np * 64, 0.f);
@@ -84,6 +85,10 @@ int main(int argc, char** argv) {
   }
   timeit("stream W only, gate pattern", 66e6 * 4 / 4, [&](int) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
   timeit("stream W only, wave-contiguous", 66e6, [&](int) { hipLaunchKernelGGL(k_stream<1>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
+  timeit("stream W, node stride +256 B", 66e6, [&](int) { hipLaunchKernelGGL(k_stream<2>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
+  timeit("stream W, node stride +1280 B", 66e6, [&](int) { hipLaunchKernelGGL(k_stream<3>, dim3(N), dim3(512), 0, s, Wg, ZH, nG); });
+  timeit("stream W, nG=16 (128 KB stride)", 53e6, [&](int) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, Wg, ZH, 16); });
+  timeit("stream W, nG=16 stride +256 B", 53e6, [&](int) { hipLaunchKernelGGL(k_stream<2>, dim3(N), dim3(512), 0, s, Wg, ZH, 16); });
   timeit("stream G only (26 MB)", 26e6, [&](int) { hipLaunchKernelGGL(k_stream<1>, dim3(N), dim3(512), 0, s, G, ZH, 8); });
   timeit("stream W alternating 2 sets", 66e6, [&](int i) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, (i & 1) ? Wg2 : Wg, ZH, nG); });
   timeit("gate16 (same W every launch)", fg, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a); });
