@@ -49,6 +49,9 @@ WORKLOADS = {
                   desc="Baltimore 403-node, in=24h out=24h, batch=64/GPU, multi+unidirection K=5"),
     "dc237": dict(nodes=237, batch=64, out=12, city="DC",
                   desc="DC 237-node, in=24h out=12h, batch=64/GPU, multi+unidirection K=5"),
+    # BASELINE config 5 (stress): synthetic 4096-node graph, 32 samples per GPU (256 over 8 GPUs)
+    "synth4096": dict(nodes=4096, batch=32, out=24, city="BM",
+                      desc="synthetic 4096-node random .rel + learned adaptive adj, in=24h out=24h, batch=32/GPU, K=5"),
 }
 
 
@@ -256,7 +259,7 @@ def main():
             "mae_at_12": mae12,
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "synth4096":   # (hours of CPU time at N=4096)
             base, pred_cpu = cpu_baseline(w, seed, x_np, dict(model.named_parameters()), df, pred)
             result["cpu_baseline"] = base
             result["mae_at_12_cpu"] = float(masked_mae(pred_cpu[:, min(12, w["out"]) - 1],

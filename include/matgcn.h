@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 5
+#define MATGCN_ABI_VERSION 6
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -176,6 +176,21 @@ int matgcn_encoder_fwd(const matgcn_dims* dims, const matgcn_params* params, con
 int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                        const float* seq, float* out, void* workspace, size_t workspace_bytes,
                        void* stream);
+
+/* ---- loss / metric epilogue ---------------------------------------------------------------------
+ * De-scale, mask and reduce on the device (MultiATGCN.calculate_loss, MultiATGCN.py:422-427, with
+ * loss.masked_mae_torch, libcity/model/loss.py:17-29; TrafficStateEvaluator "single" mode MAE@k,
+ * libcity/evaluator/traffic_state_evaluator.py:87-104).  For an affine scaler x -> x*std + mean:
+ *   l = y*std + mean, p = pred*std + mean;  l := 0 where |l| < min_s;
+ *   mask = (l != null_val)   [null_val NaN: mask = !isnan(l)]
+ *   result[0]     = sum(|p-l|*mask) / sum(mask)              (the masked-MAE loss over all horizons)
+ *   result[1 + k] = the same restricted to horizon k          (MAE@k+1)
+ * pred (B, out, N, od) contiguous; y (B, y_steps >= out, N, y_feat), channels y_start .. y_start+od-1.
+ * partials: caller-owned device scratch of 2*B*out floats; result: device, 1+out floats.  Two launches, fixed
+ * summation order (no atomics): results are run-to-run identical. */
+int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
+                      int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
+                      float* partials, float* result, void* stream);
 
 /* ---- scheduling option ------------------------------------------------------------------------
  * The encoder runs the recurrent chains of the layers as a wavefront on internal HIP streams (created once, on

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "matgcn_encoder_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, _P,
                                      C.c_size_t, _P]),
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_masked_mae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
@@ -101,8 +103,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 5:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 5" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 6:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 6" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

@@ -549,6 +549,21 @@ extern "C" {
 
 int matgcn_abi_version(void) { return MATGCN_ABI_VERSION; }
 
+int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
+                      int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
+                      float* partials, float* result, void* stream) {
+  if (!pred || !y || !partials || !result) return MATGCN_ERR_NULL;
+  if (batch < 1 || out_steps < 1 || out_steps > 64 || nodes < 1 || out_dim < 1 || y_steps < out_steps ||
+      y_start < 0 || y_start + out_dim > y_feat)
+    return MATGCN_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mae_partial, dim3((unsigned)(batch * out_steps)), dim3(256), 0, s, pred, y, out_steps, nodes,
+                     out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s, partials);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_mae_final, dim3(1), dim3(64), 0, s, partials, batch, out_steps, result);
+  return launch_ok();
+}
+
 int matgcn_set_wavefront(int enabled) {
   const int prev = g_wavefront_on ? 1 : 0;
   g_wavefront_on = enabled != 0;

@@ -665,3 +665,54 @@ __global__ __launch_bounds__(64) void k_head(HeadArgs a) {
     }
   }
 }
+
+// =================================================================================================
+// 9. loss / metric epilogue (MultiATGCN.py:422-427, loss.py:17-29, traffic_state_evaluator.py:87-104)
+// =================================================================================================
+// stage 1: one workgroup per (b, horizon): sum |p-l|*mask and sum mask over the N*od values of that slab
+__global__ __launch_bounds__(256) void k_mae_partial(const float* __restrict__ pred, const float* __restrict__ y,
+                                                     int outSteps, int N, int od, int ySteps, int yFeat, int yStart,
+                                                     float mean, float std, float nullVal, float minS,
+                                                     float* __restrict__ partials) {
+  __shared__ float sAbs[256], sCnt[256];
+  const int b = blockIdx.x / outSteps, o = blockIdx.x - b * outSteps;
+  const float* pp = pred + ((size_t)b * outSteps + o) * N * od;
+  const float* yp = y + ((size_t)b * ySteps + o) * N * yFeat + yStart;
+  const bool nanMask = nullVal != nullVal;
+  float sa = 0.f, sc = 0.f;
+  for (int idx = threadIdx.x; idx < N * od; idx += 256) {
+    const int n = idx / od, c = idx - n * od;
+    float l = yp[(size_t)n * yFeat + c] * std + mean;
+    const float p = pp[idx] * std + mean;
+    if (fabsf(l) < minS) l = 0.f;                       // loss.py:18 (the reference does this in place)
+    const float m = nanMask ? (l == l ? 1.f : 0.f) : (l != nullVal ? 1.f : 0.f);
+    const float d = fabsf(p - l) * m;
+    sa += (d == d) ? d : 0.f;                           // nan -> 0 (loss.py:27)
+    sc += m;
+  }
+  sAbs[threadIdx.x] = sa; sCnt[threadIdx.x] = sc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sAbs[threadIdx.x] += sAbs[threadIdx.x + s]; sCnt[threadIdx.x] += sCnt[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sAbs[0]; partials[2 * blockIdx.x + 1] = sCnt[0]; }
+}
+
+// stage 2: one workgroup: thread o sums horizon o over the batch in fp64, thread 0 then the total
+__global__ __launch_bounds__(64) void k_mae_final(const float* __restrict__ partials, int B, int outSteps,
+                                                  float* __restrict__ result) {
+  __shared__ double hAbs[64], hCnt[64];
+  const int o = threadIdx.x;
+  double sa = 0.0, sc = 0.0;
+  if (o < outSteps)
+    for (int b = 0; b < B; ++b) { sa += partials[2 * (b * outSteps + o)]; sc += partials[2 * (b * outSteps + o) + 1]; }
+  hAbs[o] = sa; hCnt[o] = sc;
+  if (o < outSteps) result[1 + o] = sc > 0.0 ? (float)(sa / sc) : 0.f;
+  __syncthreads();
+  if (o == 0) {
+    double ta = 0.0, tc = 0.0;
+    for (int k = 0; k < outSteps; ++k) { ta += hAbs[k]; tc += hCnt[k]; }
+    result[0] = tc > 0.0 ? (float)(ta / tc) : 0.f;      // all-masked: mask/mean(mask) is nan -> 0 (loss.py:24-27)
+  }
+}

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import graph_prep
-from .ops import HotPath, PathSpec, diagonal_mask, spec_from_config
+from .ops import HotPath, PathSpec, diagonal_mask, masked_mae_device, spec_from_config
 
 try:  # inside a LibCity checkout: subclass the real plugin base so isinstance checks hold
     from libcity.model.abstract_traffic_state_model import AbstractTrafficStateModel  # type: ignore
@@ -237,10 +237,41 @@ class MultiATGCN(AbstractTrafficStateModel):
         hp = self._path_for_batch(int(label_start.shape[0]), series.device)
         return hp.forward_series(series, label_start.to(torch.int32), rel_steps)
 
+    def _affine_scaler(self):
+        """(mean, std) when the scaler de-scales as x*std + mean with scalar parameters (LibCity's StandardScaler /
+        NoneScaler, libcity/utils/normalization.py:62-76), else None."""
+        sc = self._scaler
+        mean, std = getattr(sc, "mean", None), getattr(sc, "std", None)
+        if mean is None and std is None and type(sc).__name__ == "NoneScaler":
+            return 0.0, 1.0
+        try:
+            mean, std = float(mean), float(std)
+        except (TypeError, ValueError):
+            return None
+        probe = sc.inverse_transform(torch.tensor([0.0, 1.0]))
+        if abs(float(probe[0]) - mean) > 1e-6 * max(1.0, abs(mean)) or \
+                abs(float(probe[1]) - (mean + std)) > 1e-6 * max(1.0, abs(mean + std)):
+            return None
+        return mean, std
+
     def calculate_loss(self, batch):
-        """de-scale prediction and label, masked MAE with null value 0 (:422-427)."""
+        """de-scale prediction and label, masked MAE with null value 0 (:422-427).  With an affine scaler the
+        de-scale + mask + reduction run fused on the device; any other scaler takes the reference's torch
+        arithmetic on the HIP prediction."""
         y_true = batch["y"]
         y_predicted = self.predict(batch)
+        affine = self._affine_scaler()
+        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32:
+            return masked_mae_device(y_predicted, y_true, self.start_dim, affine[0], affine[1], null_val=0.0)[0]
         y_true = self._scaler.inverse_transform(y_true[..., self.start_dim:self.end_dim])
         y_predicted = self._scaler.inverse_transform(y_predicted)
         return masked_mae(y_predicted, y_true, 0)
+
+    def horizon_mae(self, batch):
+        """(out,) device tensor MAE@1..MAE@out in the evaluator's "single" mode on de-scaled values
+        (traffic_state_executor.py:268-273, traffic_state_evaluator.py:87-104), without leaving the GPU."""
+        affine = self._affine_scaler()
+        if affine is None:
+            raise NotImplementedError("horizon_mae needs an affine scaler (StandardScaler / NoneScaler)")
+        pred = self.predict(batch)
+        return masked_mae_device(pred, batch["y"], self.start_dim, affine[0], affine[1])[1:]

@@ -143,6 +143,26 @@ def _check_tensor(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
     return t.contiguous()
 
 
+def masked_mae_device(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
+                      null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
+    """(1 + out,) tensor [masked-MAE over all horizons, MAE@1 .. MAE@out] computed on the device by
+    matgcn_masked_mae (de-scale + mask + reduce; reference loss.py:17-29, traffic_state_evaluator.py:87-104)."""
+    lib = _lib.load()
+    pred = _check_tensor(pred, "pred")
+    y = _check_tensor(y, "y")
+    b, out, n, od = pred.shape
+    if y.dim() != 4 or y.shape[0] != b or y.shape[2] != n:
+        raise _lib.MatgcnError("y has shape %s, incompatible with pred %s" % (tuple(y.shape), tuple(pred.shape)))
+    partials = torch.empty(2 * b * out, dtype=torch.float32, device=pred.device)
+    result = torch.empty(1 + out, dtype=torch.float32, device=pred.device)
+    stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
+    _lib.check(lib.matgcn_masked_mae(C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), b, out, n, od,
+                                     int(y.shape[1]), int(y.shape[3]), int(y_start), float(mean), float(std),
+                                     float(null_val), float(min_s), C.c_void_p(partials.data_ptr()),
+                                     C.c_void_p(result.data_ptr()), stream), "matgcn_masked_mae")
+    return result
+
+
 class HotPath:
     """One (spec, batch) binding.  Not thread-safe; uses torch's current stream at call time."""
 

@@ -56,3 +56,37 @@ def test_grad_mode_is_refused(lib_built):
     m, dev = _model(c)
     with pytest.raises(NotImplementedError):
         m.predict({"X": torch.from_numpy(c.x).to(dev)})
+
+
+def test_fused_loss_and_horizon_mae_with_a_real_scaler(lib_built):
+    """matgcn_masked_mae (de-scale + mask + reduce on the device) vs the torch arithmetic of the reference
+    (loss.py:17-29) with Baltimore's flow statistics as scaler and some exactly-zero / tiny labels."""
+    from multistgraph_amd import synthetic as syn
+    from multistgraph_amd.model import MultiATGCN, masked_mae
+    c = Case("tiny_multi_uni_out12")
+    dev = torch.device("cuda:0")
+    scaler = syn.PlainScaler(14.41, 29.3)
+    m = MultiATGCN(c.config("cuda:0"), dict(c.data_feature, scaler=scaler)).to(dev).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+    y = torch.from_numpy(c.y).clone()
+    y[0, :, :3, 0] = -14.41 / 29.3            # de-scales to exactly 0 -> masked out of the loss
+    y[1, 2, 5, 0] = (5e-5 - 14.41) / 29.3     # |label| < 1e-4 after de-scaling -> zeroed, then masked
+    batch = {"X": torch.from_numpy(c.x).to(dev), "y": y.to(dev)}
+    with torch.no_grad():
+        pred = m.predict(batch)
+        loss = m.calculate_loss(batch)
+        mae = m.horizon_mae(batch)
+    p = scaler.inverse_transform(pred.cpu())
+    want = masked_mae(p, scaler.inverse_transform(y[..., 0:1].clone()), 0)
+    assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
+    for k in range(c.out):
+        w = masked_mae(p[:, k], scaler.inverse_transform(y[:, k, :, 0:1].clone()))
+        assert abs(mae[k].item() - w.item()) <= 2e-6 * abs(w.item())
+    # a scaler that is not affine falls back to the reference's torch arithmetic
+    class Cubic:
+        def inverse_transform(self, d):
+            return d * d * d
+    m._scaler = Cubic()
+    with torch.no_grad():
+        l2 = m.calculate_loss(batch)
+    assert torch.isfinite(l2)
