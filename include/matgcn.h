@@ -196,7 +196,8 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
  * The encoder runs the recurrent chains of the layers as a wavefront on internal HIP streams (created once, on
  * first use; forked from and joined back into the caller's stream with events, so the caller still sees one
  * in-order stream).  matgcn_set_wavefront(0) serialises everything on the caller's stream instead - same kernels,
- * same results; used to time one kernel alone.  Returns the previous setting. */
+ * same results; used to time one kernel alone.  (A lock-step pairing of the chains through per-kernel events was
+ * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting. */
 int matgcn_set_wavefront(int enabled);
 
 /* ---- measurement hooks (bench.py; not on the hot path) ---------------------------------------

@@ -207,7 +207,7 @@ struct Wavefront {
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
 };
 Wavefront g_wf;
-bool g_wavefront_on = true;   // matgcn_set_wavefront
+int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
 
 int wavefront_ready() {
   if (g_wf.ready) return MATGCN_OK;
@@ -223,6 +223,7 @@ int wavefront_ready() {
       HIP_OK(hipEventCreateWithFlags(&g_wf.xdone[l][t], hipEventDisableTiming));
     }
   }
+
   g_wf.ready = true;
   return MATGCN_OK;
 }
@@ -318,34 +319,29 @@ void fill_res_args(const Ctx& c, int l, const float* xt, long xRowStride, const 
   a->blend = blend; a->seq = seq_t; a->seqRowStride = (long)P.Np * H;
 }
 
-// One recurrent step of layer l at step t on the layer's state Hx_l:
-//   mix(h) -> gate -> mix(z*h) -> update [+ residual GRU cell + blend when `res` is set]   (MultiATGCN.py:120-128,
-//   142-150, 205-208).  raw: optional (B,N,128) dump of the gate pre-activation; gateOnly stops after the gate.
-int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node16Args* res, hipStream_t s) {
+// phase 0: mix(h) -> G;  1: gate;  2: mix(z*h) -> G;  3: update [+ residual cell + blend when `res` is set]
+int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Args* res, hipStream_t s) {
   const Plan& P = c.P;
   const float* St = c.prep + P.oSt;
   float* Hx = c.ws + P.oHx[l];
   float* ZHx = c.ws + P.oZHx[l];
   float* G = c.ws + P.oG[l];
   float* R = c.ws + P.oR[l];
-  RETURN_IF(mix_rows(P, St, Hx, P.B, G, s, true));
+  if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true);
+  if (phase == 2) return mix_rows(P, St, ZHx, P.B, G, s, true);
   Node16Args a;
   memset(&a, 0, sizeof(a));
-  a.s = Hx; a.g = G; a.w = c.prep + P.oWg[l];
+  a.g = G; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
   else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.B * 192;
-  a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
-  a.zh = ZHx; a.r = R; a.raw = raw;
   const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
-  {
+  if (phase == 1) {
+    a.s = Hx; a.w = c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
     hipLaunchKernelGGL(k_gate16, grid, dim3(512), P.nodeLds, s, a);
+    return launch_ok();
   }
-  CHECK_LAUNCH();
-  if (gateOnly) return MATGCN_OK;
-  RETURN_IF(mix_rows(P, St, ZHx, P.B, G, s, true));
-  a.s = ZHx; a.w = c.prep + P.oWu[l]; a.raw = nullptr; a.zh = nullptr;
-  a.h = Hx; a.hout = Hx;
+  a.s = ZHx; a.w = c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
   ProfScope prof(MATGCN_PROF_UPDATE, s);
   if (res) {
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
@@ -356,6 +352,17 @@ int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node1
     hipLaunchKernelGGL(k_update16<0>, grid, dim3(512), P.nodeLds, s, a);
   }
   return launch_ok();
+}
+
+// One recurrent step of layer l at step t on the layer's state Hx_l:
+//   mix(h) -> gate -> mix(z*h) -> update [+ residual GRU cell + blend when `res` is set]   (MultiATGCN.py:120-128,
+//   142-150, 205-208).  raw: optional (B,N,128) dump of the gate pre-activation; gateOnly stops after the gate.
+int cell_step(const Ctx& c, int l, int t, float* raw, bool gateOnly, const Node16Args* res, hipStream_t s) {
+  RETURN_IF(cell_phase(c, l, t, 0, raw, res, s));
+  RETURN_IF(cell_phase(c, l, t, 1, raw, res, s));
+  if (gateOnly) return MATGCN_OK;
+  RETURN_IF(cell_phase(c, l, t, 2, nullptr, res, s));
+  return cell_phase(c, l, t, 3, nullptr, res, s);
 }
 
 // residual GRU cell alone (unit entry point): Hx_l <- cell(x_t, Hx_l)
@@ -382,7 +389,7 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
   RETURN_IF(node_kernels_ready(P.nodeLds));
   RETURN_IF(wavefront_ready());
   Wavefront& W = g_wf;
-  const bool multi = P.L > 1 && g_wavefront_on;
+  const bool multi = P.L > 1 && g_wavefront_mode != 0;
   if (multi) {
     HIP_OK(hipEventRecord(W.fork, c.s));
     for (int l = 1; l < P.L; ++l) {
@@ -564,9 +571,9 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
   return launch_ok();
 }
 
-int matgcn_set_wavefront(int enabled) {
-  const int prev = g_wavefront_on ? 1 : 0;
-  g_wavefront_on = enabled != 0;
+int matgcn_set_wavefront(int mode) {
+  const int prev = g_wavefront_mode;
+  g_wavefront_mode = mode != 0 ? 1 : 0;
   return prev;
 }
 
