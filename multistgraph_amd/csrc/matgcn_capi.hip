@@ -230,11 +230,12 @@ int wavefront_ready() {
 
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
-               float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s, bool stepRole = false) {
+               float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s, bool stepRole = false,
+               long outFloats = 0) {
   if (Ks <= 0 || rowsM <= 0) return MATGCN_OK;   // every support folded away: nothing to mix
   MixArgs a;
   a.St = St; a.ldS = P.Mp; a.X = X; a.xTileStride = xTileStride; a.ldX = ldX;
-  a.out = out; a.sN = sN; a.sK = sK; a.sT = sT;
+  a.out = out; a.sN = sN; a.sK = sK; a.sT = sT; a.outFloats = outFloats;
   a.Np = P.Np; a.N = P.N; a.Ks = Ks; a.nK = P.Np / 16; a.nColTiles = nColTiles;
   a.nRowTiles = (int)(rup(rowsM, 64) / 64);
   ProfScope prof(stepRole ? MATGCN_PROF_MIX : MATGCN_PROF_MIX_PRE, s);
@@ -246,7 +247,7 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
 // mix of `rows` contiguous [Np][64] slabs into the node-major buffer G [N][rows][Ks][64]
 int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s, bool stepRole = false) {
   return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, (long)rows * P.Ks * H, H, (long)P.Ks * H, P.Ks,
-                    P.Ks * P.Np, s, stepRole);
+                    P.Ks * P.Np, s, stepRole, (long)P.N * rows * P.Ks * H);
 }
 
 struct Ctx {

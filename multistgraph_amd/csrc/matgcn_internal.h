@@ -61,6 +61,7 @@ struct MixArgs {
   int ldX;
   float* out;
   long sN, sK, sT;
+  long outFloats;        // extent of `out` (bounds the write-through buffer descriptor; 0: plain stores)
   int Np, N, Ks, nK, nColTiles, nRowTiles;
 };
 

@@ -17,6 +17,7 @@
 #include "matgcn_internal.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -467,12 +468,34 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
     }
     __syncthreads();
   }
-  float* obase = a.out + (size_t)colTile * a.sT + wc * 32 + i;
+  // Epilogue: each wave turns its 32x32 accumulator tile through LDS (the K-loop buffers are free after the last
+  // barrier; 16-byte slots XOR-swizzled by row so both the scalar writes and the b128 reads are conflict-free)
+  // and writes whole 128-byte row segments with 16-byte WRITE-THROUGH stores (sc1): the 20-75 MB this kernel
+  // produces then leave the L2 while it is still computing instead of as one dirty-line flush at its end, which
+  // the next kernel of the chain would otherwise wait for.
+  float* stg = (w < 2 ? &As[0][0] : &Bs[0][0]) + (w & 1) * 1024;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = row0 + wr * 32 + acc_row(r, half);
+    const int lrow = acc_row(r, half);
+    stg[lrow * 32 + (((i >> 2) ^ (lrow & 7)) << 2) + (i & 3)] = acc[r];
+  }
+  const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lrow = u * 8 + (lane >> 3), q = lane & 7;
+    const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+    const int row = row0 + wr * 32 + lrow;
     const int k = row / a.Np, n = row - k * a.Np;
-    if (k < a.Ks && n < a.N) obase[(size_t)n * a.sN + (size_t)k * a.sK] = acc[r];
+    if (k < a.Ks && n < a.N) {
+      const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
+      if (wt) {
+        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
+      } else {
+        *reinterpret_cast<float4*>(a.out + off) = v;
+      }
+    }
   }
 }
 

@@ -60,6 +60,18 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+typedef unsigned int u32x4_n16 __attribute__((ext_vector_type(4)));
+
+// 16-byte WRITE-THROUGH (sc1) store: the outputs of a step kernel are the next kernel's inputs, so they should
+// leave the L2 while this kernel still runs instead of as a dirty-line flush at its end (scalar sc1 stores would
+// cost a fabric write each: outputs are therefore turned into whole 256-byte rows in LDS first)
+// `base` must be wave-uniform (the descriptor lives in SGPRs); `off` is this lane's float offset (< 2^29)
+__device__ __forceinline__ void store_wt16(float* base, size_t off, const float4& v) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
+  const u32x4_n16 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
+}
+
 // position (in floats) of element (row, col) of a swizzled [.][16*blocks slots] tile with `spr` slots per row
 __device__ __forceinline__ int swz(int row, int col, int spr) {
   const int slot = col >> 2;
@@ -197,18 +209,30 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
       }
     }
   }
+  // epilogue: zr = sigmoid(.), z*h and r gathered as a [64 rows][z*h 64 | r 64] tile in LDS (the mixed slots are
+  // dead once every wave has left the K loop), then written out as whole 256-byte rows
+  __syncthreads();
+  float* Out = Gs;                                  // [64][32 slots], same XOR swizzle as the tiles
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
-      if (b >= a.rows) continue;
       const float v = acc[rt][e];
-      if (a.raw) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
+      if (a.raw && b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
       const float sg = sigmoid16(v);
-      if (w < 4) a.zh[((size_t)b * a.Np + n) * 64 + o] = sg * Hs[swz(lb, o, 16)];
-      else a.r[((size_t)n * a.rows + b) * 64 + (o - 64)] = sg;
+      Out[swz(lb, o, 32)] = (w < 4) ? sg * Hs[swz(lb, o, 16)] : sg;
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                  // 64 rows x 32 slots = 2048 float4 over 512 threads
+    const int idx = tid + 512 * it;
+    const int lb = idx >> 5, q = idx & 31, b = rowBase + lb;
+    if (b >= a.rows) continue;
+    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 32 + ((q & ~15) | ((q ^ lb) & 15))) * 4]);
+    if (q < 16) store_wt16(a.zh, ((size_t)b * a.Np + n) * 64 + q * 4, v);
+    else store_wt16(a.r, ((size_t)n * a.rows + b) * 64 + (q - 16) * 4, v);
   }
 }
 
@@ -431,20 +455,30 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
       for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].w, wv.w, acc2[q]);
     }
   }
+  // the new state is gathered as a [64][64] tile in LDS (over x_t, dead once every wave has left GEMM 2) and
+  // written to the state and to Seq_l[t] as whole 256-byte rows
+  __syncthreads();
+  float* Out = XT;
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int lb = (2 * rp + q) * 16 + 4 * kq + e, b = rowBase + lb;
-      if (b >= a.rows) continue;
+      const int lb = (2 * rp + q) * 16 + 4 * kq + e;
       const float hc = tanhf(acc2[q][e] + bu);
       const float hp = Hs[swz(lb, o4, 16)];
       const float rr = R2[swz(lb, o4, 16)];
       const float res = rr * hp + (1.0f - rr) * hc;
-      const float hn = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
-      a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn;
-      if (a.seq) a.seq[(size_t)b * a.seqRowStride + (size_t)n * 64 + o4] = hn;
+      Out[swz(lb, o4, 16)] = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
     }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {                  // 64 rows x 16 slots = 1024 float4 over 512 threads
+    const int lb = srow + 32 * it, b = rowBase + lb;
+    if (b >= a.rows) continue;
+    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (sq ^ (lb & 15))) * 4]);
+    store_wt16(a.hout, ((size_t)b * a.Np + n) * 64 + sq * 4, v);
+    if (a.seq) store_wt16(a.seq, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4, v);
+  }
 }
 
 // ---- parameter-only: the node-adaptive weight streams are written by k_prep_stream (matgcn_kernels.hip) ----
