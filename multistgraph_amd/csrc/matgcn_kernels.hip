@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // 5. graph mix GEMM (MultiATGCN.py:106):  out[(k,n)][col] = sum_m S_k[n][m] * X[m][col]
 // =================================================================================================
 // 64 x 64 output tile per workgroup, 4 waves, each one 32x32 MFMA accumulator; K-step 16 staged through
-// LDS (register-prefetched double buffer, one barrier per step).  A = St (k-major, so the tile is 16 rows of
+// LDS (double buffer, fed from registers that run two tiles ahead of the MFMAs; one barrier per step).  A = St (k-major, so the tile is 16 rows of
 // 256 contiguous bytes), B = 64 feature columns of one state row (256-byte lines).  Workgroups that share an
 // XCD (id % 8) sweep the row tiles of one column tile back to back, so St and that X slice stay in its L2.
 // ROLE only names the instantiation (0: pre-passes and Chebyshev products, 1: the recurrent step's mix of h / z*h),
@@ -443,30 +443,41 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int kk = tid >> 4, sg = tid & 15;
   const float* ap = a.St + (size_t)kk * a.ldS + row0 + sg * 4;
   const float* bp = a.X + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
-  float4 ra = *reinterpret_cast<const float4*>(ap);
-  float4 rb = *reinterpret_cast<const float4*>(bp);
-  *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = ra;
-  *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = rb;
+  // K-tile t+1 waits in registers while tile t is multiplied, and tile t+2 is already requested: two register
+  // sets alternate (the loop is unrolled by two so that they stay named registers), loads are unconditional
+  // (clamped to the last tile) so the compiler keeps counting them instead of draining the queue at a branch
+  const int last = a.nK - 1;
+  auto ldA = [&](int t) { return *reinterpret_cast<const float4*>(ap + (size_t)min(t, last) * 16 * a.ldS); };
+  auto ldB = [&](int t) { return *reinterpret_cast<const float4*>(bp + (size_t)min(t, last) * 16 * a.ldX); };
+  {
+    const float4 a0 = ldA(0), b0 = ldB(0);
+    *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = a0;
+    *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = b0;
+  }
+  float4 ra0 = ldA(1), rb0 = ldB(1), ra1 = ldA(2), rb1 = ldB(2);
   __syncthreads();
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int it = 0; it < a.nK; ++it) {
-    const int cur = it & 1;
-    const bool more = (it + 1) < a.nK;
-    if (more) {
-      ra = *reinterpret_cast<const float4*>(ap + (size_t)(it + 1) * 16 * a.ldS);
-      rb = *reinterpret_cast<const float4*>(bp + (size_t)(it + 1) * 16 * a.ldX);
-    }
+  auto mma = [&](int cur) {
     const float* A = &As[cur][half * 64 + wr * 32 + i];
     const float* Bm = &Bs[cur][half * 64 + wc * 32 + i];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc = MFMA32(A[s * 128], Bm[s * 128], acc);
-    if (more) {
-      *reinterpret_cast<float4*>(&As[cur ^ 1][kk * 64 + sg * 4]) = ra;
-      *reinterpret_cast<float4*>(&Bs[cur ^ 1][kk * 64 + sg * 4]) = rb;
-    }
+  };
+  for (int it = 0; it < a.nK; it += 2) {
+    mma(0);                                                   // tile it
+    *reinterpret_cast<float4*>(&As[1][kk * 64 + sg * 4]) = ra0;   // tile it+1 (a clamped copy past the end: unused)
+    *reinterpret_cast<float4*>(&Bs[1][kk * 64 + sg * 4]) = rb0;
+    ra0 = ldA(it + 3); rb0 = ldB(it + 3);
     __syncthreads();
+    if (it + 1 < a.nK) {
+      mma(1);                                                 // tile it+1
+      *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = ra1;   // tile it+2
+      *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = rb1;
+      ra1 = ldA(it + 4); rb1 = ldB(it + 4);
+      __syncthreads();
+    }
   }
   // Epilogue: each wave turns its 32x32 accumulator tile through LDS (the K-loop buffers are free after the last
   // barrier; 16-byte slots XOR-swizzled by row so both the scalar writes and the b128 reads are conflict-free)
