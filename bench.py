@@ -221,7 +221,7 @@ def main():
             with open(tpath) as fh:
                 traffic = json.load(fh)
         times = conc
-        roofline = dict(bound="mfma", kernel="k_mix", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
+        roofline = dict(bound="mfma", kernel="k_mix<1>", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
                         unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS,
                         traffic=(traffic or {}).get("hbm_bytes_per_launch"),
                         traffic_detail=traffic,
