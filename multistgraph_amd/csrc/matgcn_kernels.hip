@@ -18,6 +18,8 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // =================================================================================================
 // 5. graph mix GEMM (MultiATGCN.py:106):  out[(k,n)][col] = sum_m S_k[n][m] * X[m][col]
 // =================================================================================================
-// 64 x 64 output tile per workgroup, 4 waves, each one 32x32 MFMA accumulator; K-step 16 staged through
+// 64 x 64 output tile per workgroup, 4 waves, each a 32x32 tile as 2x2 accumulators of the 16x16x4 MFMA; K-step 16 staged through
 // LDS (double buffer, fed from registers that run two tiles ahead of the MFMAs; one barrier per step).  A = St (k-major, so the tile is 16 rows of
 // 256 contiguous bytes), B = 64 feature columns of one state row (256-byte lines).  Workgroups that share an
 // XCD (id % 8) sweep the row tiles of one column tile back to back, so St and that X slice stay in its L2.
@@ -439,10 +441,13 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   }
   const int row0 = rowTile * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1, i = lane & 31, half = lane >> 5;
+  const int wr = w >> 1, wc = w & 1, j = lane & 15, kq = lane >> 4;
   const int kk = tid >> 4, sg = tid & 15;
   const float* ap = a.St + (size_t)kk * a.ldS + row0 + sg * 4;
   const float* bp = a.X + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
+  // LDS image of a K-tile: row kk (one reduction index, 64 values) rotated by 16*(kk&3) floats, so that the four
+  // k rows one 16x16x4 MFMA step reads (kq = 0..3) sit in four different bank quarters
+  const int stPos = kk * 64 + (((sg + 4 * (kk & 3)) & 15) << 2);
   // K-tile t+1 waits in registers while tile t is multiplied, and tile t+2 is already requested: two register
   // sets alternate (the loop is unrolled by two so that they stay named registers), loads are unconditional
   // (clamped to the last tile) so the compiler keeps counting them instead of draining the queue at a branch
@@ -451,30 +456,43 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   auto ldB = [&](int t) { return *reinterpret_cast<const float4*>(bp + (size_t)min(t, last) * 16 * a.ldX); };
   {
     const float4 a0 = ldA(0), b0 = ldB(0);
-    *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = a0;
-    *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = b0;
+    *reinterpret_cast<float4*>(&As[0][stPos]) = a0;
+    *reinterpret_cast<float4*>(&Bs[0][stPos]) = b0;
   }
   float4 ra0 = ldA(1), rb0 = ldB(1), ra1 = ldA(2), rb1 = ldB(2);
   __syncthreads();
-  f32x16 acc;
+  // the wave's 32x32 output tile = 2x2 accumulators of v_mfma_f32_16x16x4_f32: 20 independent accumulator chains
+  // per SIMD at 5 resident workgroups per CU, enough to keep the matrix pipe issuing back to back
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int rotA0 = (wr * 32 + j + 16 * kq) & 63, rotA1 = (wr * 32 + 16 + j + 16 * kq) & 63;
+  const int rotB0 = (wc * 32 + j + 16 * kq) & 63, rotB1 = (wc * 32 + 16 + j + 16 * kq) & 63;
   auto mma = [&](int cur) {
-    const float* A = &As[cur][half * 64 + wr * 32 + i];
-    const float* Bm = &Bs[cur][half * 64 + wc * 32 + i];
+    const float* A = &As[cur][kq * 64];
+    const float* Bm = &Bs[cur][kq * 64];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = MFMA32(A[s * 128], Bm[s * 128], acc);
+    for (int s = 0; s < 4; ++s) {      // reduction indices 4s + kq of this K-tile
+      const float a0 = A[s * 256 + rotA0], a1 = A[s * 256 + rotA1];
+      const float b0 = Bm[s * 256 + rotB0], b1 = Bm[s * 256 + rotB1];
+      acc[0][0] = MFMA16(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA16(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA16(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA16(a1, b1, acc[1][1]);
+    }
   };
   for (int it = 0; it < a.nK; it += 2) {
-    mma(0);                                                   // tile it
-    *reinterpret_cast<float4*>(&As[1][kk * 64 + sg * 4]) = ra0;   // tile it+1 (a clamped copy past the end: unused)
-    *reinterpret_cast<float4*>(&Bs[1][kk * 64 + sg * 4]) = rb0;
+    mma(0);                                               // tile it
+    *reinterpret_cast<float4*>(&As[1][stPos]) = ra0;      // tile it+1 (a clamped copy past the end: unused)
+    *reinterpret_cast<float4*>(&Bs[1][stPos]) = rb0;
     ra0 = ldA(it + 3); rb0 = ldB(it + 3);
     __syncthreads();
     if (it + 1 < a.nK) {
-      mma(1);                                                 // tile it+1
-      *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = ra1;   // tile it+2
-      *reinterpret_cast<float4*>(&Bs[0][kk * 64 + sg * 4]) = rb1;
+      mma(1);                                             // tile it+1
+      *reinterpret_cast<float4*>(&As[0][stPos]) = ra1;    // tile it+2
+      *reinterpret_cast<float4*>(&Bs[0][stPos]) = rb1;
       ra1 = ldA(it + 4); rb1 = ldB(it + 4);
       __syncthreads();
     }
@@ -486,10 +504,14 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   // the next kernel of the chain would otherwise wait for.
   float* stg = (w < 2 ? &As[0][0] : &Bs[0][0]) + (w & 1) * 1024;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int lrow = acc_row(r, half);
-    stg[lrow * 32 + (((i >> 2) ^ (lrow & 7)) << 2) + (i & 3)] = acc[r];
-  }
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lrow = p * 16 + 4 * kq + e, lcol = q * 16 + j;
+        stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
+      }
   const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
 #pragma unroll

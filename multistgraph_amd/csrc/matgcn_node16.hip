@@ -18,8 +18,7 @@
 #ifndef MATGCN_NODE16_HIP
 #define MATGCN_NODE16_HIP
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// f32x4 / MFMA16 come from matgcn_kernels.hip (same translation unit)
 
 #define N16_RING 10   // k-groups of weights in flight per wave (10 KB): covers an Infinity-Cache round trip
 
