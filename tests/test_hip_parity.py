@@ -159,3 +159,25 @@ def test_wavefront_and_serial_schedules_agree_bitwise(lib_built):
     b = hp.forward(x).cpu().numpy()
     hp.lib.matgcn_set_wavefront(prev)
     assert np.array_equal(a, b)
+
+
+def test_full_size_batch_properties(lib_built):
+    """BASELINE-size properties that need no reference run (Baltimore 403 nodes, B = 64, wavefront schedule):
+    the forward is run-to-run bit-identical, and batch items are independent - permuting the batch permutes the
+    predictions bit for bit, and a sample's prediction does not depend on what else is in the batch."""
+    from multistgraph_amd import synthetic as syn
+    c = Case("bm403_out24")
+    c.b = 64
+    c.x, c.y = syn.make_batch_arrays(64, c.n, c.out, 123, feat=c.feat)
+    hp, dev = _path(c, lib_built)
+    x = torch.from_numpy(c.x).to(dev)
+    a = hp.forward(x).clone()
+    b = hp.forward(x)
+    assert torch.equal(a, b)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(dev)
+    p = hp.forward(x[perm].contiguous())
+    assert torch.equal(p, a[perm])
+    x2 = x.clone()
+    x2[1:] = torch.roll(x2[1:], 1, dims=0)          # sample 0 keeps its place, the rest of the batch changes
+    assert torch.equal(hp.forward(x2)[0], a[0])
+    assert torch.isfinite(a).all()
