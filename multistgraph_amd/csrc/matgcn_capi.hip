@@ -672,7 +672,18 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
       iPrev1 = iOut;
     }
   }
-  // node-adaptive weights
+  // node-adaptive weights: independent of the support stack and of each other, so the per-(layer, part) pieces
+  // go to the library's internal streams (forked from / joined into the caller's stream) and overlap
+  RETURN_IF(wavefront_ready());
+  Wavefront& W = g_wf;
+  hipStream_t pool[3] = {c.s, W.chain[1], W.xpart[1]};
+  const bool fork = g_wavefront_mode != 0;
+  if (fork) {
+    HIP_OK(hipEventRecord(W.fork, c.s));
+    HIP_OK(hipStreamWaitEvent(pool[1], W.fork, 0));
+    HIP_OK(hipStreamWaitEvent(pool[2], W.fork, 0));
+  }
+  int piece = 0;
   StackMap map;
   memset(&map, 0, sizeof(map));
   map.KtotOrig = P.KtotOrig; map.N = P.N;
@@ -696,6 +707,7 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
       const int nG = 4 * P.Ktot;
+      hipStream_t ws = fork ? pool[(++piece) % 3] : c.s;
       PrepStream q;
       memset(&q, 0, sizeof(q));
       q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
@@ -706,21 +718,21 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
       q.nodeStride = (long)(nG + P.nGx[l]) * 16 * O;
       q.baseOfs = 0; q.kind = 0; q.iOfs = P.Cl[l]; q.groups = nG;
       hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
-                         c.s, q);
+                         ws, q);
       CHECK_LAUNCH();
       if (l == 0) {  // folded x rows + bias row, appended to the node stream
         q.baseOfs = (long)nG * 16 * O; q.kind = 1; q.iOfs = 0; q.groups = P.nGx[0];
         hipLaunchKernelGGL(k_prep_stream<1>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
-                           c.s, q);
+                           ws, q);
         CHECK_LAUNCH();
       } else {
         // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
         q.out = prep + P.oWx[l]; q.nodeStride = P.wxStride; q.baseOfs = 0;
         q.kind = 2; q.iOfs = 0; q.groups = P.Ktot * H / 8; q.OTdst = 6; q.otOfs = part == 0 ? 0 : 4;
         hipLaunchKernelGGL(k_prep_stream<2>, dim3(blocks_for((size_t)q.groups * (O / 32) * 64), nodeGroups), dim3(256), 0,
-                           c.s, q);
+                           ws, q);
         CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, c.s, params->node_emb,
+        hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, ws, params->node_emb,
                            ap.bias_pool, P.d, O, P.N, prep + P.oBx[l], 192, part == 0 ? 0 : 128);
         CHECK_LAUNCH();
       }
@@ -735,7 +747,14 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   }
   hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.headT * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
                      params->end_conv_weight, P.headT * H, P.CH, 0, 0, P.headT * H, P.NTc, prep + P.oHead);
-  return launch_ok();
+  CHECK_LAUNCH();
+  if (fork) {
+    HIP_OK(hipEventRecord(W.done[1], pool[1]));
+    HIP_OK(hipEventRecord(W.done[2], pool[2]));
+    HIP_OK(hipStreamWaitEvent(c.s, W.done[1], 0));
+    HIP_OK(hipStreamWaitEvent(c.s, W.done[2], 0));
+  }
+  return MATGCN_OK;
 }
 
 int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
