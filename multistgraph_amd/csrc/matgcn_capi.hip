@@ -268,6 +268,7 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
 }
@@ -297,16 +298,12 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
   const int rows = P.B * nt;
   float* GX = c.ws + P.oGX[l];
   RETURN_IF(mix_rows(P, c.prep + P.oSt, xin, rows, GX, s));
-  NodeArgs a;
-  memset(&a, 0, sizeof(a));
-  a.ident = xin; a.identRowStride = (long)P.Np * H;
-  a.g = GX; a.Ks = P.Ks;
-  a.w = c.prep + P.oWx[l]; a.wNodeStride = P.wxStride;
-  a.rows = rows; a.N = P.N; a.Np = P.Np; a.B = P.B;
-  a.bias = c.prep + P.oBx[l];
+  Px16Args a;
+  a.x = xin; a.g = GX; a.w = c.prep + P.oWx[l]; a.bias = c.prep + P.oBx[l];
   a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.B * 192;
+  a.rows = rows; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks; a.B = P.B;
   ProfScope prof(MATGCN_PROF_PX, s);
-  hipLaunchKernelGGL(k_px, dim3(P.N, (unsigned)((rows + 63) / 64)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_px16, dim3((unsigned)(rup(P.N, 8) * ((rows + 63) / 64))), dim3(512), P.nodeLds, s, a);
   return launch_ok();
 }
 
@@ -726,10 +723,10 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
                            ws, q);
         CHECK_LAUNCH();
       } else {
-        // hoisted x part: gate tiles 0..3, update tiles 4..5 of a 192-wide fragment row (32x32x2 order, k_px)
+        // hoisted x part: gate column tiles 0..7, update tiles 8..11 of a 192-wide fragment row (k_px16)
         q.out = prep + P.oWx[l]; q.nodeStride = P.wxStride; q.baseOfs = 0;
-        q.kind = 2; q.iOfs = 0; q.groups = P.Ktot * H / 8; q.OTdst = 6; q.otOfs = part == 0 ? 0 : 4;
-        hipLaunchKernelGGL(k_prep_stream<2>, dim3(blocks_for((size_t)q.groups * (O / 32) * 64), nodeGroups), dim3(256), 0,
+        q.kind = 0; q.iOfs = 0; q.groups = nG; q.OTdst = 12; q.otOfs = part == 0 ? 0 : 8;
+        hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
                            ws, q);
         CHECK_LAUNCH();
         hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, ws, params->node_emb,

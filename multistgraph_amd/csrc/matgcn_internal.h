@@ -34,10 +34,10 @@ struct PrepStream {
   int d, I, O, N;
   int kind;              // 0: recurrent rows, 16x16x4 order   rows kk -> slot kk/64, channel iOfs + kk%64
                          // 1: layer-0 folded x rows, 16x16x4 order   rows kk -> slot kk/C0, channel kk%C0, then bias row
-                         // 2: x rows of layers >= 1, 32x32x2 order (k_px)   rows j -> slot j/64, channel iOfs + j%64
   int iOfs, C0;
-  int groups;            // k-groups (kinds 0/1: of 16 rows; kind 2: of 8 rows)
-  int OTdst, otOfs;      // kind 2: tiles per fragment row in the destination, first tile of this piece
+  int groups;            // k-groups of 16 rows
+  int OTdst, otOfs;      // OTdst > 0: tiles per fragment row in the destination and first tile of this piece
+                         // (the 192-column x-part stream takes the gate in tiles 0..7 and the update in 8..11)
   StackMap map;
 };
 
@@ -63,22 +63,6 @@ struct MixArgs {
   long sN, sK, sT;
   long outFloats;        // extent of `out` (bounds the write-through buffer descriptor; 0: plain stores)
   int Np, N, Ks, nK, nColTiles, nRowTiles;
-};
-
-struct NodeArgs {        // k_px: hoisted x-part of layers >= 1
-  const float* xa;       // unused (kept for the shared main loop): folded rows or null
-  long xaNodeStride, xaRowStride;
-  int xaLen;
-  const float* ident;    // identity slot rows: [row][Np][64] (+ n*64)
-  long identRowStride;
-  const float* g;        // mixed slots [N][rows][Ks][64]
-  int Ks;
-  const float* w;        // fragment-ordered (32x32x2) x-part weights, per node
-  long wNodeStride;
-  int rows;              // rows per node = B * (steps of the chunk)
-  int N, Np, B;          // B: batch rows per step (row -> (t, b), t-major)
-  const float* bias;     // [N][192]
-  float* pxOut;          // [Tc][N][B][192] slice of PX
 };
 
 struct HeadArgs {

@@ -141,10 +141,10 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
   const int nBase = blockIdx.y * PREP_NB;
   const int unit = blockIdx.x * 256 + threadIdx.x;
-  const int OT = KIND == 2 ? (a.O >> 5) : (a.O >> 4);
+  const int OT = a.O >> 4;
   if (unit >= a.groups * OT * 64) return;
   const int lane = unit & 63, ct = (unit >> 6) % OT, g = (unit >> 6) / OT;
-  const int o = KIND == 2 ? 32 * ct + (lane & 31) : 16 * ct + (lane & 15);
+  const int o = 16 * ct + (lane & 15);
   // decode the 4 rows of this lane's float4
   int slot[4], chan[4];   // kept slot (-1: zero row, -2: bias row) and input channel
 #pragma unroll
@@ -157,9 +157,6 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
       const int nx = a.map.nKeep * a.C0;
       if (kk < nx) { slot[s] = kk / a.C0; chan[s] = kk - slot[s] * a.C0; }
       else { slot[s] = kk == nx ? -2 : -1; chan[s] = 0; }
-    } else {
-      const int jj = 8 * g + 4 * (lane >> 5) + s;
-      slot[s] = jj >> 6; chan[s] = a.iOfs + (jj & 63);
     }
   }
   // softmax over the stack weights (tiny)
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
     }
   }
   size_t frag;
-  if (KIND == 2) frag = ((size_t)(g * a.OTdst + a.otOfs + ct) * 64 + lane) * 4;
+  if (a.OTdst > 0) frag = ((size_t)(g * a.OTdst + a.otOfs + ct) * 64 + lane) * 4;
   else frag = (size_t)unit * 4;
 #pragma unroll
   for (int b = 0; b < PREP_NB; ++b) {
@@ -528,151 +525,6 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
       } else {
         *reinterpret_cast<float4*>(a.out + off) = v;
       }
-    }
-  }
-}
-
-// =================================================================================================
-// 6. node-wise contraction (MultiATGCN.py:108) - shared main loop
-// =================================================================================================
-// For one node n and a tile of 64 rows (batch items): acc[row][o] += sum_j A[row][j] * W_n[j][o], where the
-// reduction index j runs over up to three row segments (folded x-part | identity slot | Ks mixed slots).
-// A chunks of 64 rows x 32 are staged in LDS (row stride 36 floats: the ds_read_b128 of lane (row, half) is
-// conflict-free); the weight chunk is already in fragment order, so its LDS image is lane-linear.
-struct SegList {  // fields, not arrays: runtime-indexed arrays would live in scratch memory
-  const float *b0, *b1, *b2;
-  long st0, st1, st2;
-  int len0, len1, len2;
-};
-
-// chunk c (32 reduction indices, the last one of a segment may be shorter) -> source row base/stride, offset, groups
-__device__ __forceinline__ void decode_chunk(const SegList& S, int c, const float*& base, long& stride, int& off,
-                                             int& ng) {
-  const int n0 = (S.len0 + 31) >> 5, n1 = (S.len1 + 31) >> 5;
-  int len;
-  if (c < n0) { base = S.b0; stride = S.st0; len = S.len0; }
-  else if (c < n0 + n1) { c -= n0; base = S.b1; stride = S.st1; len = S.len1; }
-  else { c -= n0 + n1; base = S.b2; stride = S.st2; len = S.len2; }
-  off = c << 5;
-  const int rem = len - off;
-  ng = (rem >= 32 ? 32 : rem) >> 3;
-}
-
-#define AS_STRIDE 36
-
-template <int OT, int NT>
-__device__ __forceinline__ void node_mainloop(const SegList& S, int rowBase, int rowsTotal,
-                                              const float* __restrict__ wnode, int ot0, int bt, float* As,
-                                              float* Ws, f32x16 (&acc)[NT]) {
-  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
-  const int total = ((S.len0 + 31) >> 5) + ((S.len1 + 31) >> 5) + ((S.len2 + 31) >> 5);
-  float4 ra[2], rw[OT];
-  int gofs = 0;
-  auto load = [&](int c) -> int {
-    const float* base;
-    long stride;
-    int off, ng;
-    decode_chunk(S, c, base, stride, off, ng);
-    const int per = ng * 2;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = tid + 256 * u;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < 64 * per) {
-        const int row = idx / per, q = idx - row * per;
-        const int gr = rowBase + row;
-        if (gr < rowsTotal) v = *reinterpret_cast<const float4*>(base + (long)gr * stride + off + q * 4);
-      }
-      ra[u] = v;
-    }
-    const float4* wp = reinterpret_cast<const float4*>(wnode + (size_t)gofs * OT * 256);
-#pragma unroll
-    for (int u = 0; u < OT; ++u) {
-      const int idx = tid + 256 * u;
-      rw[u] = (idx < ng * OT * 64) ? wp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    gofs += ng;
-    return ng;
-  };
-  int ngCur = load(0);
-  for (int c = 0; c < total; ++c) {
-    {
-      const int per = ngCur * 2;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = tid + 256 * u;
-        if (idx < 64 * per) {
-          const int row = idx / per, q = idx - row * per;
-          *reinterpret_cast<float4*>(&As[row * AS_STRIDE + q * 4]) = ra[u];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < OT; ++u) {
-        const int idx = tid + 256 * u;
-        if (idx < ngCur * OT * 64) *reinterpret_cast<float4*>(&Ws[idx * 4]) = rw[u];
-      }
-    }
-    __syncthreads();
-    int ngNext = 0;
-    if (c + 1 < total) ngNext = load(c + 1);
-    for (int g = 0; g < ngCur; ++g) {
-      const float4 a4 = *reinterpret_cast<const float4*>(&As[(bt * 32 + i) * AS_STRIDE + g * 8 + half * 4]);
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        const float4 w4 = *reinterpret_cast<const float4*>(&Ws[((g * OT + ot0 + tt) * 64 + lane) * 4]);
-        acc[tt] = MFMA32(a4.x, w4.x, acc[tt]);
-        acc[tt] = MFMA32(a4.y, w4.y, acc[tt]);
-        acc[tt] = MFMA32(a4.z, w4.z, acc[tt]);
-        acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
-      }
-    }
-    __syncthreads();
-    ngCur = ngNext;
-  }
-}
-
-__device__ __forceinline__ SegList make_segs(const NodeArgs& a, int n, const float* ident) {
-  SegList S;
-  // segment 0: folded x-part (may be empty), 1: identity slot, 2: the Ks mixed slots
-  S.b0 = a.xa ? a.xa + (size_t)n * a.xaNodeStride : nullptr;
-  S.st0 = a.xaRowStride;
-  S.len0 = a.xa ? a.xaLen : 0;
-  S.b1 = ident + (size_t)n * 64;
-  S.st1 = a.identRowStride;
-  S.len1 = 64;
-  S.b2 = a.g + (size_t)n * a.rows * a.Ks * 64;
-  S.st2 = (long)a.Ks * 64;
-  S.len2 = a.Ks * 64;
-  return S;
-}
-
-// ---- hoisted x-part for layers >= 1: PX[t][n][b][0:192] = bias[n] + [x | mix(x)] . Wx[n] ---------------------
-// Node-wise contraction with M = B*Tc rows per node (rows are (t,b) pairs of a chunk of steps, t-major),
-// O = 128 (gate) | 64 (update); 32x32x2 MFMA, A chunks and the weight chunk staged through LDS.
-__global__ __launch_bounds__(256) void k_px(NodeArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[64 * AS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Ws[4 * 6 * 64 * 4];
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, half = lane >> 5;
-  const int bt = w & 1, oh = w >> 1;
-  SegList S = make_segs(a, n, a.ident);
-  f32x16 acc[3];
-#pragma unroll
-  for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-  node_mainloop<6, 3>(S, rowBase, a.rows, a.w + (size_t)n * a.wNodeStride, oh * 3, bt, As, Ws, acc);
-  const int B = a.B;   // rows are (t, b) pairs, t-major
-#pragma unroll
-  for (int tt = 0; tt < 3; ++tt) {
-    const int o = (oh * 3 + tt) * 32 + i;
-    const float bias = a.bias[(size_t)n * 192 + o];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rowBase + bt * 32 + acc_row(r, half);
-      if (row >= a.rows) continue;
-      const int t = row / B, b = row - t * B;
-      a.pxOut[(((size_t)t * a.N + n) * B + b) * 192 + o] = acc[tt][r] + bias;
     }
   }
 }

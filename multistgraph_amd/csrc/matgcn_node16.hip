@@ -235,6 +235,95 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
   }
 }
 
+// ---- hoisted x part of layers >= 1: PX[t][n][b][0:192] = bias[n] + [x | mix_k(x)] . Wx[n] --------------------
+// (MultiATGCN.py:106-108 restricted to the x rows; gate columns 0:128, update columns 128:192.)  Same structure as
+// the gate kernel - 64-row tile [x | G] of one node in LDS, weights streamed once per workgroup - with 12 column
+// tiles over 8 waves: waves 0-3 take two tiles, waves 4-7 one, i.e. three per SIMD.  rows = B * (steps of the
+// chunk), row -> (t, b) t-major; workgroup ids of one node's row blocks are 8 apart (same XCD, same time: the
+// second and later blocks read the node's weights from that XCD's L2).
+#define PX16_RING 6
+struct Px16Args {
+  const float* x;        // [rows][Np][64] input rows of the chunk (layer below, time-major)
+  const float* g;        // [N][rows][Ks][64] graph-mixed input rows
+  const float* w;        // [N][nG][12][64][4] x rows of both AGCNs (fragment order)
+  const float* bias;     // [N][192]
+  float* pxOut;          // [Tc][N][B][192] slice of PX
+  int rows, N, Np, Ks, B;
+};
+__global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Hs = lds;
+  float* Gs = lds + 64 * 64;
+  const int RB = (p.rows + 63) >> 6;
+  const int id = blockIdx.x;
+  const int grp = id / (8 * RB), rem = id - grp * 8 * RB;
+  const int n = grp * 8 + (rem & 7), rowBase = (rem >> 3) * 64;
+  if (n >= p.N) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int nG = 4 * (1 + p.Ks);
+  const bool two = w < 4;                       // this wave also owns column tile w + 8
+  const float4* wp0 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
+  const float4* wp1 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + min(w + 8, 11)) * 64 + lane;
+  Node16Args a;                                 // staging helper speaks Node16Args
+  a.s = p.x; a.g = p.g; a.rows = p.rows; a.Np = p.Np; a.Ks = p.Ks;
+  stage_node_tile(a, n, rowBase, Hs, Gs);
+  float4 wr0[PX16_RING], wr1[PX16_RING];
+#pragma unroll
+  for (int r = 0; r < PX16_RING; ++r) {
+    wr0[r] = wp0[(size_t)min(r, nG - 1) * 12 * 64];
+    wr1[r] = wp1[(size_t)min(r, nG - 1) * 12 * 64];
+  }
+  const int o0 = 16 * w + j, o1 = 16 * (w + 8) + j;
+  const float b0 = p.bias[(size_t)n * 192 + o0], b1 = two ? p.bias[(size_t)n * 192 + o1] : 0.f;
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
+  __syncthreads();
+  for (int g0 = 0; g0 < nG; g0 += PX16_RING) {
+#pragma unroll
+    for (int r = 0; r < PX16_RING; ++r) {
+      const int g = g0 + r;
+      const float4 wv0 = wr0[r], wv1 = wr1[r];
+      wr0[r] = wp0[(size_t)min(g + PX16_RING, nG - 1) * 12 * 64];
+      wr1[r] = wp1[(size_t)min(g + PX16_RING, nG - 1) * 12 * 64];
+      if (g < nG) {
+        float4 av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, p.Ks, rt, g, j, kq);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
+        if (two) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = rowBase + rt * 16 + 4 * kq + e;
+      if (row >= p.rows) continue;
+      const int t = row / p.B, b = row - t * p.B;
+      float* dst = p.pxOut + (((size_t)t * p.N + n) * p.B + b) * 192;
+      dst[o0] = acc0[rt][e];
+      if (two) dst[o1] = acc1[rt][e];
+    }
+}
+
 // ---- update AGCN + tanh + GRU blend, fused with the residual GRU cell and the per-step blend ------------------
 // MODE 0: ATGRU update only (h' out); 1: update + residual cell (+ blend); 2: residual cell only on s (unit entry)
 //
