@@ -83,6 +83,8 @@ _SIGNATURES = {
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "matgcn_profile_disable": (C.c_int, []),
 }
+# matgcn_profile_* kernel kinds (MATGCN_PROF_*): k_mix = k_mix<1> (per-step graph mix), k_mix_pre = k_mix<0>,
+# k_gate = k_gate16, k_update = k_update16<0|1> (update [+ residual cell]), k_res_gru = k_update16<2>, k_px = k_px16
 PROF_KINDS = {1: "k_mix", 2: "k_gate", 4: "k_update", 8: "k_res_gru", 16: "k_px", 32: "k_head", 64: "k_mix_pre"}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

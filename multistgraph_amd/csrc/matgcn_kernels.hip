@@ -1,16 +1,20 @@
 // matgcn_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the Multi-ATGCN forward path.
 //
 // Every kernel cites the reference lines (libcity/model/traffic_flow_prediction/MultiATGCN.py) whose
-// arithmetic it implements.  All matrix contractions run on the exact-fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32): lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
-// the 16 accumulator registers of lane l hold C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+// arithmetic it implements.  All matrix contractions run on the exact-fp32 matrix cores:
+//   v_mfma_f32_16x16x4_f32 (graph mix, node kernels): lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
+//     its 4 accumulator registers hold C[row = 4*(l>>4) + e][col = l&15];
+//   v_mfma_f32_32x32x2_f32 (output head): A[row = l&31][k = l>>5], B[k = l>>5][col = l&31];
+//     its 16 accumulator registers hold C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+// This file: support stack, weight-stream preparation, layout helpers, head fusion, the graph-mix GEMM, the output
+// head and the loss epilogue; the node-wise step kernels live in matgcn_node16.hip (same translation unit).
 //
-// Data layout (all fp32, Np = N rounded up to 16, H = 64):
-//   St   [Np][Mp]            transposed support stack, column k*Np+n holds S_k[n][.]   (mix A operand)
-//   Hx   [rows][Np][64]      recurrent state / any per-row node features              (mix B operand)
-//   G    [N][rows][Ks][64]   graph-mixed features, node-major                          (node GEMM A operand)
-//   W*   [N][K/8][OT][64][4] node-adaptive weights in MFMA B-fragment order            (node GEMM B operand)
-//   PX   [T][N][B][192]      hoisted x-part of gate|update pre-activations (+bias)
+// Data layout (all fp32, Np = N rounded up to 16, H = 64; DESIGN.md section 3 has the full tables):
+//   St   [Np][Mp]              transposed dense support stack, column k*Np+n holds S_k[n][.]   (mix A operand)
+//   Hx   [rows][Np][64]        recurrent state / any per-row node features                    (mix B operand)
+//   G    [N][rows][Ks][64]     graph-mixed features, node-major                                (node GEMM A operand)
+//   W*   [N][K/16][OT][64][4]  node-adaptive weights in 16x16x4 B-fragment order               (node GEMM B operand)
+//   PX   [T][N][B][192]        hoisted x-part of gate|update pre-activations (+bias), layers >= 1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
