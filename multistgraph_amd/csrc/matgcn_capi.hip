@@ -494,7 +494,7 @@ int head_padded(const Ctx& c, const float* seqp, float* out) {
   a.bias = c.prm->end_conv_bias; a.out = out;
   a.B = P.B; a.T = P.headT; a.N = P.N; a.Np = P.Np; a.CH = P.CH; a.od = P.od; a.NTc = P.NTc;
   ProfScope prof(MATGCN_PROF_HEAD, c.s);
-  hipLaunchKernelGGL(k_head, dim3((unsigned)(P.B * ((P.N + 31) / 32))), dim3(64), 0, c.s, a);
+  hipLaunchKernelGGL(k_head, dim3((unsigned)(P.B * ((P.N + 31) / 32))), dim3(256), 0, c.s, a);
   return launch_ok();
 }
 

@@ -536,12 +536,15 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
 // =================================================================================================
 // 8. output head (MultiATGCN.py:416-418): Conv2d(T -> out*od, (1,H)) == [B*N x T*H] . [T*H x CH]
 // =================================================================================================
-// One wave per (b, 32-node tile); A fragments straight from the padded time-major sequence [T][B][Np][64] (each
-// lane walks its node's 256-byte rows), B = fragment-ordered conv weight from L2.  out[b][o][n][dd] with channel ch = o*od + dd.
-__global__ __launch_bounds__(64) void k_head(HeadArgs a) {
+// One workgroup of 4 waves per (b, 32-node tile): the waves split the T steps of the reduction (t = w, w+4, ..)
+// so four times as many loads are in flight per tile, and add their partial tiles in LDS in a fixed order.
+// A fragments come straight from the padded time-major sequence [T][B][Np][64] (each lane walks its node's
+// 256-byte rows), B = fragment-ordered conv weight from L2.  out[b][o][n][dd] with channel ch = o*od + dd.
+__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+  __shared__ f32x16 part[3][2][64];      // partial accumulators of waves 1..3
   const int tilesPerB = (a.N + 31) >> 5;
   const int b = blockIdx.x / tilesPerB, n0 = (blockIdx.x % tilesPerB) * 32;
-  const int lane = threadIdx.x, i = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 31, half = lane >> 5;
   const int node = min(n0 + i, a.Np - 1);  // pad rows are zero / in bounds
   f32x16 acc[2];
 #pragma unroll
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(64) void k_head(HeadArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
   const int nt = a.NTc;
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = w; t < a.T; t += 4) {
     const float* rowp = a.seq + (((size_t)t * a.B + b) * a.Np + node) * 64 + half * 4;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -563,6 +566,15 @@ __global__ __launch_bounds__(64) void k_head(HeadArgs a) {
         acc[tt] = MFMA32(a4.w, w4.w, acc[tt]);
       }
     }
+  }
+  if (w > 0) { part[w - 1][0][lane] = acc[0]; part[w - 1][1][lane] = acc[1]; }
+  __syncthreads();
+  if (w > 0) return;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const f32x16 p0 = part[q][0][lane], p1 = part[q][1][lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] += p0[r]; acc[1][r] += p1[r]; }
   }
   // accumulator rows = nodes, cols = channels
   for (int tt = 0; tt < nt; ++tt) {
