@@ -33,6 +33,87 @@ __global__ __launch_bounds__(512) void k_stream(const float* __restrict__ w, flo
   if (acc.x == 123.456f) out[threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// K-loop probes: 8 waves per workgroup, 20 k-groups x 16 MFMAs per wave, features added one at a time
+//   0: operands in registers   1: A fragments from the swizzled LDS tile   2: + weights from a global ring
+//   3: + the runtime (g < nG) guard of the product kernel
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_probe(const float* __restrict__ wsrc, float* __restrict__ out, int nG, int Ks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Hs = lds; float* Gs = lds + 64 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < 64 * 64 * (1 + Ks); i += 512) lds[i] = 0.001f * (i & 255);
+  const float4* wp = reinterpret_cast<const float4*>(wsrc) + ((size_t)blockIdx.x * nG * 8 + w) * 64 + lane;
+  float4 wr[N16_RING];
+#pragma unroll
+  for (int r = 0; r < N16_RING; ++r) wr[r] = (MODE >= 2) ? wp[(size_t)min(r, nG - 1) * 8 * 64] : make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+  f32x4 acc[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float4 creg[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) creg[rt] = make_float4(0.5f + rt, 0.25f, 0.125f, 1.0f);
+  if (MODE == 4) {
+    float4 avA[4], avB[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, Ks, rt, 0, j, kq);
+    auto mm = [&](float4 (&av)[4], const float4& wv) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+    };
+    for (int g0 = 0; g0 < nG; g0 += N16_RING) {
+#pragma unroll
+      for (int r = 0; r < N16_RING; r += 2) {
+        const int g = g0 + r;
+        const float4 w0 = wr[r], w1 = wr[r + 1];
+        wr[r] = wp[(size_t)min(g + N16_RING, nG - 1) * 8 * 64];
+        wr[r + 1] = wp[(size_t)min(g + 1 + N16_RING, nG - 1) * 8 * 64];
+        if (g < nG) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) avB[rt] = a_frag(Hs, Gs, Ks, rt, min(g + 1, nG - 1), j, kq);
+          mm(avA, w0);
+        }
+        if (g + 1 < nG) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, Ks, rt, min(g + 2, nG - 1), j, kq);
+          mm(avB, w1);
+        }
+      }
+    }
+  } else
+  for (int g0 = 0; g0 < nG; g0 += N16_RING) {
+#pragma unroll
+    for (int r = 0; r < N16_RING; ++r) {
+      const int g = g0 + r;
+      const float4 wv = wr[r];
+      if (MODE >= 2) wr[r] = wp[(size_t)min(g + N16_RING, nG - 1) * 8 * 64];
+      if (MODE < 3 || g < nG) {
+        float4 av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[rt] = (MODE >= 1) ? a_frag(Hs, Gs, Ks, rt, (MODE < 3) ? min(g, nG - 1) : g, j, kq) : creg[rt];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) sum += acc[rt][0] + acc[rt][1] + acc[rt][2] + acc[rt][3];
+  if (sum == 123.456f) out[tid] = sum;
+}
+
 int main(int argc, char** argv) {
   const int N = 403, Np = 416, Ks = 4, B = 64;
   const int nG = 4 * (1 + Ks);
@@ -41,7 +122,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < floats; i += 97) h[i] = 0.001f * (i % 1000); CK(hipMemcpy(p, h.data(), floats * 4, hipMemcpyHostToDevice)); return p; };
   float* S = dalloc((size_t)B * Np * 64, 0.1f);
   float* G = dalloc((size_t)N * B * Ks * 64, 0.1f);
-  float* Wg = dalloc((size_t)N * (nG * 16 * 128 + 1024), 0.01f);
+  float* Wg = dalloc((size_t)512 * (24 * 16 * 128 + 1024), 0.01f);
   float* Wu = dalloc((size_t)N * nG * 16 * 64, 0.01f);
   float* PX = dalloc((size_t)N * B * 192, 0.1f);
   float* ZH = dalloc((size_t)B * Np * 64, 0.f);
@@ -93,6 +174,23 @@ int main(int argc, char** argv) {
   timeit("stream W, nG=16 stride +256 B", 53e6, [&](int) { hipLaunchKernelGGL(k_stream<2>, dim3(N), dim3(512), 0, s, Wg, ZH, 16); });
   timeit("stream G only (26 MB)", 26e6, [&](int) { hipLaunchKernelGGL(k_stream<1>, dim3(N), dim3(512), 0, s, G, ZH, 8); });
   timeit("stream W alternating 2 sets", 66e6, [&](int i) { hipLaunchKernelGGL(k_stream<0>, dim3(N), dim3(512), 0, s, (i & 1) ? Wg2 : Wg, ZH, nG); });
+  {
+    const double fp = 256.0 * 8 * 24 * 16 * 2048.0;   // nG = 24 = 3 ring cycles, no guard skips
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    timeit("probe 0: register operands", fp, [&](int) { hipLaunchKernelGGL(k_probe<0>, dim3(256), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 1: + A from LDS", fp, [&](int) { hipLaunchKernelGGL(k_probe<1>, dim3(256), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 2: + W global ring", fp, [&](int) { hipLaunchKernelGGL(k_probe<2>, dim3(256), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 3: + runtime guard", fp, [&](int) { hipLaunchKernelGGL(k_probe<3>, dim3(256), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    timeit("probe 4: ping-pong A prefetch", fp, [&](int) { hipLaunchKernelGGL(k_probe<4>, dim3(256), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 4 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<4>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 3 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<3>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 1 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<1>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
+    timeit("probe 0 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<0>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
+  }
   timeit("gate16 (same W every launch)", fg, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a); });
   timeit("gate16 (alternating W sets)", fg, [&](int i) { Node16Args b2 = a; b2.w = (i & 1) ? Wg2 : Wg; hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, b2); });
   timeit("update16<1> (update+res)", fu, [&](int) { hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u); });
