@@ -20,7 +20,13 @@
 
 // f32x4 / MFMA16 come from matgcn_kernels.hip (same translation unit)
 
+#ifndef N16_RING
 #define N16_RING 10   // k-groups of weights in flight per wave (10 KB): covers an Infinity-Cache round trip
+#endif
+#ifndef U16_RING
+#define U16_RING 6    // the same for k_update16: its waves stream half as many bytes per k-group, and the
+                      // residual-cell operands need the registers (10 spills)
+#endif
 
 struct Node16Args {
   const float* s;        // [rows][Np][64]: h (gate / res-only) or z*h (update)
@@ -125,6 +131,19 @@ __device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int K
   return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
 }
 
+// the 16 MFMAs of one k-group: 4 row tiles x 4 k-steps, accumulators rotate so that a chain is revisited every
+// fourth instruction
+__device__ __forceinline__ void mfma_group(const float4 (&av)[4], const float4& wv, f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+}
+
 // layer-0 x part: acc[rt] += XA[rows of tile rt][16 gx .. +16] . Wx[gx]; A fragments come straight from global
 // memory (a row of XA is 64*nGx bytes, a 16-row tile is contiguous), weights from the tail of the node's stream
 __device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, const float4* wx, int gStride, int i,
@@ -180,31 +199,25 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
     x_groups(a, n, rowBase, wp + (size_t)nG * 8 * 64, 8 * 64, j, kq, acc);
   }
   __syncthreads();
+  // k-groups in pairs: the A fragments of a group are read from LDS while the MFMAs of the group before it run
+  // (two named fragment sets ping-pong; nG is even)
+  float4 avA[4], avB[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, 0, j, kq);
   for (int g0 = 0; g0 < nG; g0 += N16_RING) {
 #pragma unroll
-    for (int r = 0; r < N16_RING; ++r) {
+    for (int r = 0; r < N16_RING; r += 2) {
       const int g = g0 + r;
-      const float4 wv = wr[r];
-#ifndef N16_LAB_NOLOAD
+      const float4 w0 = wr[r], w1 = wr[r + 1];
       wr[r] = wp[(size_t)min(g + N16_RING, nG - 1) * 8 * 64];
-#endif
-#ifdef N16_LAB_NOMFMA
-      if (g < nG) { acc[0][0] += wv.x + wv.y + wv.z + wv.w; }
-      if (false) {
-#else
+      wr[r + 1] = wp[(size_t)min(g + 1 + N16_RING, nG - 1) * 8 * 64];
       if (g < nG) {
-#endif
-        float4 av[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, a.Ks, rt, g, j, kq);
+        for (int rt = 0; rt < 4; ++rt) avB[rt] = a_frag(Hs, Gs, a.Ks, rt, g + 1, j, kq);
+        mfma_group(avA, w0, acc);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+        for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, min(g + 2, nG - 1), j, kq);
+        mfma_group(avB, w1, acc);
       }
     }
   }
@@ -241,7 +254,9 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
 // tiles over 8 waves: waves 0-3 take two tiles, waves 4-7 one, i.e. three per SIMD.  rows = B * (steps of the
 // chunk), row -> (t, b) t-major; workgroup ids of one node's row blocks are 8 apart (same XCD, same time: the
 // second and later blocks read the node's weights from that XCD's L2).
-#define PX16_RING 6
+#ifndef PX16_RING
+#define PX16_RING 4   // two rings (two column tiles per wave); 6 spills to scratch (-11 %)
+#endif
 struct Px16Args {
   const float* x;        // [rows][Np][64] input rows of the chunk (layer below, time-major)
   const float* g;        // [N][rows][Ks][64] graph-mixed input rows
@@ -351,32 +366,31 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
     const int gBeg = kh * nGh;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
     stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
-    float4 wr[N16_RING];
+    float4 wr[U16_RING];
 #pragma unroll
-    for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)(gBeg + min(r, nGh - 1)) * 4 * 64];
+    for (int r = 0; r < U16_RING; ++r) wr[r] = wp[(size_t)(gBeg + min(r, nGh - 1)) * 4 * 64];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!a.px && kh == 0) x_groups(a, n, rowBase, wp + (size_t)nG * 4 * 64, 4 * 64, j, kq, acc);   // layer 0
     __syncthreads();
-    for (int g0 = 0; g0 < nGh; g0 += N16_RING) {
+    // k-groups in pairs, A fragments one group ahead of the MFMAs (see k_gate16); nGh is even
+    float4 avA[4], avB[4];
 #pragma unroll
-      for (int r = 0; r < N16_RING; ++r) {
+    for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg, j, kq);
+    for (int g0 = 0; g0 < nGh; g0 += U16_RING) {
+#pragma unroll
+      for (int r = 0; r < U16_RING; r += 2) {
         const int gl = g0 + r;
-        const float4 wv = wr[r];
-        wr[r] = wp[(size_t)(gBeg + min(gl + N16_RING, nGh - 1)) * 4 * 64];
+        const float4 w0 = wr[r], w1 = wr[r + 1];
+        wr[r] = wp[(size_t)(gBeg + min(gl + U16_RING, nGh - 1)) * 4 * 64];
+        wr[r + 1] = wp[(size_t)(gBeg + min(gl + 1 + U16_RING, nGh - 1)) * 4 * 64];
         if (gl < nGh) {
-          const int g = gBeg + gl;
-          float4 av[4];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, a.Ks, rt, g, j, kq);
+          for (int rt = 0; rt < 4; ++rt) avB[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg + gl + 1, j, kq);
+          mfma_group(avA, w0, acc);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+          for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg + min(gl + 2, nGh - 1), j, kq);
+          mfma_group(avB, w1, acc);
         }
       }
     }

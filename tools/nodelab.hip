@@ -195,6 +195,17 @@ int main(int argc, char** argv) {
   timeit("gate16 (alternating W sets)", fg, [&](int i) { Node16Args b2 = a; b2.w = (i & 1) ? Wg2 : Wg; hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, b2); });
   timeit("update16<1> (update+res)", fu, [&](int) { hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u); });
   timeit("update16<0> (update only)", fu, [&](int) { hipLaunchKernelGGL(k_update16<0>, dim3(N), dim3(512), lds, s, u); });
+  {
+    const int rows = 4 * B, RB = rows / 64;
+    float* X4 = dalloc((size_t)rows * Np * 64, 0.1f);
+    float* G4 = dalloc((size_t)N * rows * Ks * 64, 0.1f);
+    float* Wp = dalloc((size_t)N * nG * 12 * 256, 0.01f);
+    float* Bp = dalloc((size_t)N * 192, 0.1f);
+    float* PX4 = dalloc((size_t)4 * N * B * 192, 0.f);
+    Px16Args p; p.x = X4; p.g = G4; p.w = Wp; p.bias = Bp; p.pxOut = PX4; p.rows = rows; p.N = N; p.Np = Np; p.Ks = Ks; p.B = B;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    timeit("px16 (4-step chunk)", 2.0 * rows * N * 320.0 * 192, [&](int) { hipLaunchKernelGGL(k_px16, dim3(((N + 7) / 8) * 8 * RB), dim3(512), lds, s, p); });
+  }
   { Node16Args b2 = a; b2.N = 256; timeit("gate16 256 nodes only", fg * 256 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(256), dim3(512), lds, s, b2); }); }
   { Node16Args b2 = a; timeit("gate16 128 nodes only", fg * 128 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(128), dim3(512), lds, s, b2); }); }
   return 0;
