@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 6
+#define MATGCN_ABI_VERSION 7
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -191,6 +191,60 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
 int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
                       int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
                       float* partials, float* result, void* stream);
+
+/* ---- training step: forward that keeps activations + backward -----------
+ * Replaces torch autograd through MultiATGCN.forward as driven by TrafficStateExecutor._train_epoch
+ * (libcity/executor/traffic_state_executor.py:411-422: loss = calculate_loss(batch); loss.backward()).
+ * matgcn_grads mirrors matgcn_params field by field (same shapes); every non-NULL gradient is OVERWRITTEN.
+ * node_emb may be NULL (node_specific_off freezes it); node_vec1/2 are required iff adp_mode == UNI.
+ * `train` is one more caller-owned device buffer of matgcn_train_bytes(): forward_train saves z, r, hc of the
+ * graph cell and z2, r2, hc2 of the residual cell of every (layer, step) into it, backward uses the rest as
+ * scratch.  matgcn_backward must see the SAME workspace and train buffers, untouched, that the matching
+ * matgcn_forward_train call used (the sequences of every layer live in the workspace).
+ * d_out (B, output_window, N, output_dim) is the gradient of the loss w.r.t. the forward's output.
+ * Reductions that meet in one address use fp32 atomics: gradients are reproducible to rounding, not bitwise.
+ * Not built yet for training (MATGCN_ERR_UNSUPPORTED): cheb_order > 2, gcn_off, fnn_off. */
+typedef struct matgcn_agcn_grads {
+  float* weights_g;
+  float* weights_pool;
+  float* bias_pool;
+} matgcn_agcn_grads;
+
+typedef struct matgcn_linear_grads {
+  float* weight;
+  float* bias;
+} matgcn_linear_grads;
+
+typedef struct matgcn_grads {
+  float* node_emb;
+  float* node_vec1;
+  float* node_vec2;
+  float* static_supports; /* unused: the static supports are constants */
+  float* weight_tsg;
+  float* weight_ts[MATGCN_MAX_HEADS];
+  float* weights_gru;
+  matgcn_agcn_grads gate[MATGCN_MAX_LAYERS];
+  matgcn_agcn_grads update[MATGCN_MAX_LAYERS];
+  matgcn_linear_grads res_gate[MATGCN_MAX_LAYERS];
+  matgcn_linear_grads res_update[MATGCN_MAX_LAYERS];
+  float* end_conv_weight;
+  float* end_conv_bias;
+} matgcn_grads;
+
+int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes);
+int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                         const float* X, float* out, void* workspace, size_t workspace_bytes, void* train,
+                         size_t train_bytes, void* stream);
+int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                    const float* d_out, const matgcn_grads* grads, void* workspace, size_t workspace_bytes,
+                    void* train, size_t train_bytes, void* stream);
+
+/* The one contraction kernel of the backward, exposed for its parity test: a strided, two-level-batched fp32
+ * GEMM  C[b1][b2] (+)= alpha * sum_{k2,k} A[b1][b2][m][k2][k] B[b1][b2][k2][k][n].  desc (22 x int64, host):
+ * M, N, K, K2, sAm, sAk, sAk2, sBk, sBn, sBk2, sCm, sCn, nb1, nb2, bA1, bA2, bB1, bB2, bC1, bC2,
+ * mode (0: C = alpha*acc + beta*C; 1: atomic add into C), split (K ranges per output tile, mode 1). */
+int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* desc, float alpha, float beta,
+                      void* stream);
 
 /* ---- scheduling option ------------------------------------------------------------------------
  * The encoder runs the recurrent chains of the layers as a wavefront on internal HIP streams (created once, on

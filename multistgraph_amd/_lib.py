@@ -78,6 +78,13 @@ _SIGNATURES = {
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
     "matgcn_masked_mae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
+    "matgcn_train_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
+    "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P,
+                                       C.c_size_t, _P]),
+    # matgcn_grads has the layout of matgcn_params (non-const pointers): the same ctypes struct serves both
+    "matgcn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.POINTER(Params), _P,
+                                  C.c_size_t, _P, C.c_size_t, _P]),
+    "matgcn_debug_gemm": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_float, C.c_float, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
@@ -105,8 +112,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 6:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 6" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 7:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 7" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

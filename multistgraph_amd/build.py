@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmatgcn.so")
 SOURCES = ["matgcn_capi.hip"]
-DEPS = ["matgcn_capi.hip", "matgcn_kernels.hip", "matgcn_node16.hip", "matgcn_internal.h",
+DEPS = ["matgcn_capi.hip", "matgcn_kernels.hip", "matgcn_node16.hip", "matgcn_bwd.hip", "matgcn_bwd_kernels.hip", "matgcn_internal.h",
         os.path.join("..", "..", "include", "matgcn.h")]
 
 

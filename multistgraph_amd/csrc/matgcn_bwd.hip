@@ -1,0 +1,511 @@
+// matgcn_bwd.hip - host schedule of the training step (included at the end of matgcn_capi.hip).
+//
+// matgcn_forward_train = matgcn_forward that also keeps z, r, hc of the graph cell and z2, r2, hc2 of the residual
+// cell of every (layer, step); matgcn_backward back-propagates d_out through the head, the encoder and the head
+// fusion down to every parameter of the reference state_dict (autograd of MultiATGCN.py:363-420).
+//
+// Schedule of the encoder backward, per layer from the top:
+//   chain  t = T-1 .. 0   only what is sequential in time: residual cell and graph cell algebra, the h columns of
+//                         both AGCNs (node GEMM with the transposed weights, transposed graph mix); the
+//                         pre-activation gradients of every step are kept
+//   batch  over all T     x columns -> gradient of the layer's input sequence; weight gradients as per-node GEMMs
+//                         with K = T*B; gradient of the adaptive adjacency; residual nn.Linear gradients
+// and at the end the parameter-only part: node-adaptive weights -> pools / node_emb / weights_g, adaptive adjacency
+// -> node_vec1/2 (or node_emb), head fusion -> weight_ts / weight_tsg.
+//
+// Not yet built for training (MATGCN_ERR_UNSUPPORTED): cheb_order > 2, gcn_off, fnn_off.
+
+namespace {
+
+GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.K2 = 1;
+  g.nb2 = 1; g.alpha = 1.f; g.beta = 0.f; g.mode = 0; g.split = 1;
+  return g;
+}
+
+int gemm(const GemmArgs& g, int nb1, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K2 <= 0 || nb1 <= 0) return MATGCN_OK;
+  const long gx = (g.N + 63) / 64, gy = (g.M + 63) / 64, gz = (long)nb1 * g.nb2 * g.split;
+  if (gy > 65535 || gz > 65535) return MATGCN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_bgemm, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), 0, s, g);
+  return launch_ok();
+}
+
+struct Bwd {
+  Ctx c;
+  const float* X;
+  const matgcn_grads* g;
+  float* tr;
+};
+
+// original stack index k -> slot of the node GEMM (kept slots in order, diagonal ones share the identity slot)
+void slot_map(const Plan& P, const StackMap& map, int* slotOf) {
+  for (int k = 0; k < P.KtotOrig; ++k) slotOf[k] = 0;
+  for (int s2 = 0; s2 < map.nKeep; ++s2) slotOf[map.keepK[s2]] = s2;
+}
+
+StackMap build_stack_map(const Plan& P, const matgcn_dims* D, const matgcn_params* params) {
+  StackMap map;
+  memset(&map, 0, sizeof(map));
+  const int per = D->cheb_k - 1;
+  map.KtotOrig = P.KtotOrig; map.N = P.N;
+  map.keepK[0] = 0; map.nKeep = 1;
+  for (int fd = 0; fd < P.nDenseFirst; ++fd)
+    for (int j = 0; j < per; ++j) map.keepK[map.nKeep++] = 1 + P.denseFirst[fd] * per + j;
+  const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
+  for (int q = 0; q < P.nDiagFirst; ++q)
+    for (int j = 0; j < per; ++j) {
+      map.diagK[map.nDiag] = 1 + P.diagFirst[q] * per + j;
+      map.diagOrder[map.nDiag] = j + 1;
+      map.diagSrc[map.nDiag] = params->static_supports + (size_t)(P.diagFirst[q] - adp) * P.N * P.N;
+      ++map.nDiag;
+    }
+  return map;
+}
+
+// dst[rows][m][i] (+)= sum_kk' St[m][kk'] * src[rows][slot 1..][kk'][i]: the transposed graph mix of the dense
+// slots of a [rows][S][Np][Cc] gradient, one GEMM batched over the rows
+int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst) {
+  const Plan& P = b.c.P;
+  if (P.Ks <= 0) return MATGCN_OK;
+  const int S = b.c.R.S;
+  GemmArgs g = gemm_args(b.c.prep + P.oSt, src + (size_t)P.Np * Cc, dst, P.N, Cc, P.Ks * P.Np);
+  g.sAm = P.Mp; g.sAk = 1;
+  g.sBk = Cc; g.sBn = 1; g.bB1 = (long)S * P.Np * Cc;
+  g.sCm = Cc; g.sCn = 1; g.bC1 = (long)P.Np * Cc;
+  return gemm(g, rows, b.c.s);
+}
+
+// dA[rows][s][n][i] (+)= dPre[rows][n][0:O] . Wp[n][s][iOfs + i][0:O]^T for every node and slot
+int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp, int I, int iOfs, int Cc, int rows,
+                         float* dA, float beta) {
+  const Plan& P = b.c.P;
+  const int S = b.c.R.S;
+  GemmArgs g = gemm_args(dPre, Wp + (size_t)iOfs * O, dA, rows, Cc, O);
+  g.sAm = (long)P.Np * O; g.sAk = 1; g.bA1 = O;
+  g.sBk = 1; g.sBn = O; g.bB1 = (long)S * I * O; g.bB2 = (long)I * O;
+  g.sCm = (long)S * P.Np * Cc; g.sCn = 1; g.bC1 = Cc; g.bC2 = (long)P.Np * Cc;
+  g.nb2 = S; g.beta = beta;
+  return gemm(g, P.N, b.c.s);
+}
+
+// dWp[n][s][iOfs + i][o] = sum_rows [U | mix(U)][rows][n][s][i] * dPre[rows][n][o]
+int node_weight_grad(const Bwd& b, const float* U, const float* Gall, int Cc, const float* dPre, int O, int I, int iOfs,
+                     int rows, float* dWp) {
+  const Plan& P = b.c.P;
+  const int S = b.c.R.S;
+  {  // identity slot: the rows themselves
+    GemmArgs g = gemm_args(U, dPre, dWp + (size_t)iOfs * O, Cc, O, rows);
+    g.sAm = 1; g.sAk = (long)P.Np * Cc; g.bA1 = Cc;
+    g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O;
+    g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O;
+    RETURN_IF(gemm(g, P.N, b.c.s));
+  }
+  if (P.Ks > 0) {  // dense slots: the mixed rows
+    GemmArgs g = gemm_args(Gall, dPre, dWp + (size_t)I * O + (size_t)iOfs * O, Cc, O, rows);
+    g.sAm = 1; g.sAk = (long)P.Ks * P.Np * Cc; g.bA1 = Cc; g.bA2 = (long)P.Np * Cc;
+    g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O; g.bB2 = 0;
+    g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O; g.bC2 = (long)I * O;
+    g.nb2 = P.Ks;
+    RETURN_IF(gemm(g, P.N, b.c.s));
+  }
+  return MATGCN_OK;
+}
+
+// Gall[rows][kk'][i] = sum_m S_k[n][m] U[rows][m][i]  (all dense slots, all rows)
+int mix_all(const Bwd& b, const float* U, int rows, int Cc, float* Gall) {
+  const Plan& P = b.c.P;
+  if (P.Ks <= 0) return MATGCN_OK;
+  GemmArgs g = gemm_args(b.c.prep + P.oSt, U, Gall, P.Ks * P.Np, Cc, P.N);
+  g.sAm = 1; g.sAk = P.Mp;
+  g.sBk = Cc; g.sBn = 1; g.bB1 = (long)P.Np * Cc;
+  g.sCm = Cc; g.sCn = 1; g.bC1 = (long)P.Ks * P.Np * Cc;
+  return gemm(g, rows, b.c.s);
+}
+
+// dT[n][m] += sum_{rows, i} dA[rows][slot 1][n][i] * U[rows][m][i]   (first dense slot = the adaptive adjacency)
+int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int Cc, float* dT) {
+  const Plan& P = b.c.P;
+  const int S = b.c.R.S;
+  GemmArgs g = gemm_args(dA + (size_t)P.Np * Cc, U, dT, P.N, P.N, Cc);
+  g.K2 = rows;
+  g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;
+  g.sBk = 1; g.sBn = Cc; g.sBk2 = (long)P.Np * Cc;
+  g.sCm = P.N; g.sCn = 1;
+  g.mode = 1; g.split = 48;
+  return gemm(g, 1, b.c.s);
+}
+
+// nn.Linear weight gradient: dW[o][iOfs + i] = sum_rows dPre[rows][o] * In[rows][i]   (rows = every (t, b, n))
+int linear_weight_grad(const Bwd& b, const float* dPre, int O, const float* In, int Cc, long rows, int I, int iOfs,
+                       float* dW) {
+  GemmArgs g = gemm_args(dPre, In, dW + iOfs, O, Cc, (int)rows);   // rows < 2^31 is checked by the caller
+  g.sAm = 1; g.sAk = O;
+  g.sBk = Cc; g.sBn = 1;
+  g.sCm = I; g.sCn = 1;
+  g.mode = 1; g.split = 256;
+  return gemm(g, 1, b.c.s);
+}
+
+int backward_impl(Bwd& b, const float* dOut) {
+  const Ctx& c = b.c;
+  const Plan& P = c.P;
+  const TrainPlan& R = c.R;
+  const matgcn_dims* D = c.D;
+  const matgcn_params* prm = c.prm;
+  const matgcn_grads* g = b.g;
+  float* tr = b.tr;
+  hipStream_t s = c.s;
+  const int S = R.S, T = P.T, B = P.B, Np = P.Np, N = P.N;
+  const long slab = (long)B * Np * H;
+  const int rowsTB = T * B;
+  if (D->cheb_k > 2 || P.gcnOff || P.headT != T) return MATGCN_ERR_UNSUPPORTED;
+  if ((long)rowsTB * Np >= (1L << 31)) return MATGCN_ERR_UNSUPPORTED;
+  const bool adp = D->adp_mode != MATGCN_ADP_NONE;
+  // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
+
+  // ---- scratch and outputs start from zero ----
+  RETURN_IF(zero_async(tr + R.savedFloats, R.floats - R.savedFloats, s));
+  auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
+  RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
+  RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
+  if (!g->weights_gru || !g->weight_tsg || !g->end_conv_weight || !g->end_conv_bias) return MATGCN_ERR_NULL;
+
+  const StackMap map = build_stack_map(P, D, prm);
+  int slotOf[MATGCN_MAX_STACK];
+  slot_map(P, map, slotOf);
+
+  // plain folded weights of both AGCNs of every layer
+  for (int l = 0; l < P.L; ++l)
+    for (int part = 0; part < 2; ++part) {
+      const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
+      PlainPrep q;
+      memset(&q, 0, sizeof(q));
+      q.E = prm->node_emb; q.wpool = ap.weights_pool; q.wg = D->scale_by_g ? ap.weights_g : nullptr;
+      q.out = tr + R.oWp[l][part];
+      q.d = P.d; q.I = P.Cl[l] + H; q.O = part == 0 ? 128 : 64; q.N = N; q.S = S; q.map = map;
+      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)S * q.I * q.O), (unsigned)N), dim3(256), 0, s, q);
+      CHECK_LAUNCH();
+    }
+
+  // ---- output head (MultiATGCN.py:416-418) ----
+  float* dOutRows = tr + R.oDOutRows;
+  hipLaunchKernelGGL(k_dout_rows, dim3(blocks_for((size_t)B * Np * P.CH)), dim3(256), 0, s, dOut, dOutRows, B,
+                     P.CH / P.od, N, Np, P.od);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_colsum_all, dim3((unsigned)P.CH), dim3(256), 0, s, dOutRows, (size_t)B, N, Np, P.CH,
+                     g->end_conv_bias);
+  CHECK_LAUNCH();
+  const float* seqTop = c.ws + P.oSeq[P.L - 1];
+  float* dSeq = tr + R.oDSeq[0];
+  {
+    GemmArgs q = gemm_args(dOutRows, prm->end_conv_weight, dSeq, N, H, P.CH);
+    q.sAm = P.CH; q.sAk = 1; q.bA2 = (long)Np * P.CH;
+    q.sBk = (long)T * H; q.sBn = 1; q.bB1 = H;
+    q.sCm = H; q.sCn = 1; q.bC1 = slab; q.bC2 = (long)Np * H;
+    q.nb2 = B;
+    RETURN_IF(gemm(q, T, s));
+    RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * T * H, s));
+    GemmArgs w = gemm_args(dOutRows, seqTop, g->end_conv_weight, P.CH, H, N);
+    w.K2 = B;
+    w.sAm = 1; w.sAk = P.CH; w.sAk2 = (long)Np * P.CH;
+    w.sBk = H; w.sBn = 1; w.sBk2 = (long)Np * H; w.bB1 = slab;
+    w.sCm = (long)T * H; w.sCn = 1; w.bC1 = H;
+    w.mode = 1; w.split = 16;
+    RETURN_IF(gemm(w, T, s));
+  }
+
+  float* dT = tr + R.oDT;
+  int cur = 0;
+  for (int l = P.L - 1; l >= 0; --l) {
+    const int C = P.Cl[l], I = C + H;
+    const float* seq = c.ws + P.oSeq[l];
+    float* dSeqCur = tr + R.oDSeq[cur];
+    float* DPU = tr + R.oDPU; float* DPG = tr + R.oDPG; float* DPU2 = tr + R.oDPU2; float* DPG2 = tr + R.oDPG2;
+    float* DAg = tr + R.oDAg; float* DAu = tr + R.oDAu;
+    float* DH = tr + R.oDH; float* DHa = tr + R.oDHa; float* TMP = tr + R.oTmp; float* MixOut = tr + R.oMixOut;
+    const float* WpG = tr + R.oWp[l][0];
+    const float* WpU = tr + R.oWp[l][1];
+    const float* RG = prm->res_gate[l].weight;     // (128, I)
+    const float* RU = prm->res_update[l].weight;   // (64, I)
+    // ---------------- chain ----------------
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t at = (size_t)t * slab;
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : DH; a.hprev = t > 0 ? seq + at - slab : nullptr;
+      a.z = tr + R.oZ[l] + at; a.r = tr + R.oR[l] + at; a.hc = tr + R.oHC[l] + at;
+      a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
+      a.blend = prm->weights_gru + (size_t)l * T + t; a.dblend = g->weights_gru + (size_t)l * T + t;
+      a.dha = DHa; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dpu = DPU + at; a.dpg = DPG + 2 * at;
+      a.dzh2 = TMP; a.dzhA = DAu + at * S; a.dzhMix = P.Ks > 0 ? MixOut : nullptr;
+      a.dhA = DAg + at * S; a.dhMix = P.Ks > 0 ? MixOut : nullptr;
+      a.dh = DH; a.dr = tr + R.oDR;
+      a.B = B; a.N = N; a.Np = Np; a.S = S;
+      const dim3 eg(blocks_for((size_t)slab));
+      hipLaunchKernelGGL(k_chain_res_out, eg, dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+      {  // gradient of z2*ha = dpre_u2 . RU[:, C:]
+        GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
+        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s));
+      }
+      hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+      {  // dha += dpre_g2 . RG[:, C:]
+        GemmArgs q = gemm_args(DPG2 + 2 * at, RG + C, DHa, B * Np, H, 128);
+        q.sAm = 128; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1; q.beta = 1.f;
+        RETURN_IF(gemm(q, 1, s));
+      }
+      hipLaunchKernelGGL(k_chain_cell_out, eg, dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+      RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
+      RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
+      hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+      RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, 0.f));
+      RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));
+      hipLaunchKernelGGL(k_chain_carry, eg, dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+    }
+    // ---------------- everything that batches over the T steps ----------------
+    const float* Xall;
+    if (l == 0) {
+      float* X0tm = tr + R.oX0tm;
+      hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, s,
+                         c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
+      CHECK_LAUNCH();
+      Xall = X0tm;
+    } else {
+      Xall = c.ws + P.oSeq[l - 1];
+    }
+    float* Hprev = tr + R.oHprev; float* ZH = tr + R.oZH; float* HA = tr + R.oHA; float* Z2HA = tr + R.oZ2HA;
+    RETURN_IF(zero_async(Hprev, slab, s));
+    if (T > 1)
+      HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const size_t seqN = (size_t)T * slab;
+    hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oZ[l], Hprev, ZH, seqN);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oR[l], Hprev, tr + R.oHC[l],
+                       tr + R.oZ2[l], HA, Z2HA, seqN);
+    CHECK_LAUNCH();
+    // x columns of both AGCNs -> gradient of the input sequence of this layer
+    float* DAx = tr + R.oDAx;
+    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
+    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
+    float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
+    RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
+    RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
+    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
+                       (size_t)rowsTB, Np, C, S);
+    CHECK_LAUNCH();
+    {  // residual cell x columns
+      GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
+      q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
+      RETURN_IF(gemm(q, 1, s));
+      GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
+      q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
+      RETURN_IF(gemm(q2, 1, s));
+    }
+    // node-adaptive weight gradients (plain folded layout) and biases
+    float* Gall = tr + R.oGall;
+    float* dWpG = tr + R.oDWp[l][0];
+    float* dWpU = tr + R.oDWp[l][1];
+    RETURN_IF(mix_all(b, Xall, rowsTB, C, Gall));
+    RETURN_IF(node_weight_grad(b, Xall, Gall, C, DPG, 128, I, 0, rowsTB, dWpG));
+    RETURN_IF(node_weight_grad(b, Xall, Gall, C, DPU, 64, I, 0, rowsTB, dWpU));
+    if (adp) RETURN_IF(adaptive_grad(b, DAx, Xall, rowsTB, C, dT));
+    RETURN_IF(mix_all(b, Hprev, rowsTB, H, Gall));
+    RETURN_IF(node_weight_grad(b, Hprev, Gall, H, DPG, 128, I, C, rowsTB, dWpG));
+    if (adp) RETURN_IF(adaptive_grad(b, DAg, Hprev, rowsTB, H, dT));
+    RETURN_IF(mix_all(b, ZH, rowsTB, H, Gall));
+    RETURN_IF(node_weight_grad(b, ZH, Gall, H, DPU, 64, I, C, rowsTB, dWpU));
+    if (adp) RETURN_IF(adaptive_grad(b, DAu, ZH, rowsTB, H, dT));
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128)), dim3(256), 0, s, DPG, (size_t)rowsTB, N, Np,
+                       128, tr + R.oDBias[l][0]);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64)), dim3(256), 0, s, DPU, (size_t)rowsTB, N, Np, 64,
+                       tr + R.oDBias[l][1]);
+    CHECK_LAUNCH();
+    // residual nn.Linear gradients (MultiATGCN.py:139-150)
+    {
+      const matgcn_linear_grads& gg = g->res_gate[l];
+      const matgcn_linear_grads& gu = g->res_update[l];
+      if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
+      RETURN_IF(zero_async(gg.weight, 128L * I, s));
+      RETURN_IF(zero_async(gu.weight, 64L * I, s));
+      const long rows = (long)rowsTB * Np;
+      RETURN_IF(linear_weight_grad(b, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+      RETURN_IF(linear_weight_grad(b, DPG2, 128, HA, H, rows, I, C, gg.weight));
+      RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+      RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
+      hipLaunchKernelGGL(k_colsum_all, dim3(128), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, gg.bias);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_colsum_all, dim3(64), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, gu.bias);
+      CHECK_LAUNCH();
+    }
+    if (l > 0) cur ^= 1;
+  }
+
+  // ---- head fusion (MultiATGCN.py:365-402) ----
+  {
+    float* dgain = tr + R.oDGain;
+    RETURN_IF(zero_async(dgain, 64, s));
+    FuseBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = b.X; a.dx0 = tr + R.oDX0; a.tsg = prm->weight_tsg; a.dgain = dgain;
+    for (int h = 0; h < D->n_heads; ++h) {
+      if (!g->weight_ts[h]) return MATGCN_ERR_NULL;
+      a.ts[h] = prm->weight_ts[h]; a.dts[h] = g->weight_ts[h]; a.headBegin[h] = D->head_begin[h];
+    }
+    a.B = B; a.T = T; a.N = N; a.Np = Np; a.C0 = P.C0; a.od = P.od; a.F = D->x_feat; a.xSteps = D->x_steps;
+    a.startDim = D->start_dim; a.nHeads = D->n_heads; a.nTs = D->n_ts;
+    hipLaunchKernelGGL(k_fuse_heads_bwd, dim3(blocks_for((size_t)T * N * P.od), (unsigned)D->n_heads), dim3(256), 0, s,
+                       a);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_softmax_bwd_small, dim3(1), dim3(64), 0, s, prm->weight_tsg, dgain, D->n_ts, g->weight_tsg);
+    CHECK_LAUNCH();
+  }
+
+  // ---- parameter-only part: node-adaptive weights -> pools, node_emb, weights_g (MultiATGCN.py:102-105) ----
+  float* EK = tr + R.oEK; float* FK = tr + R.oFK; float* TmpK = tr + R.oTmpK; float* dgain = tr + R.oDGain;
+  const int Kt = P.KtotOrig;
+  for (int l = 0; l < P.L; ++l)
+    for (int part = 0; part < 2; ++part) {
+      const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
+      const matgcn_agcn_grads& ag = part == 0 ? g->gate[l] : g->update[l];
+      if (!ag.weights_pool || !ag.bias_pool || (D->scale_by_g && !ag.weights_g)) return MATGCN_ERR_NULL;
+      const int O = part == 0 ? 128 : 64, I = P.Cl[l] + H;
+      const long IO = (long)I * O;
+      const float* wg = D->scale_by_g ? ap.weights_g : nullptr;
+      const float* dWp = tr + R.oDWp[l][part];
+      const float* dBias = tr + R.oDBias[l][part];
+      hipLaunchKernelGGL(k_scaled_emb, dim3(blocks_for((size_t)N * P.d), (unsigned)Kt), dim3(256), 0, s, prm->node_emb,
+                         wg, map, P.d, EK, FK);
+      CHECK_LAUNCH();
+      RETURN_IF(zero_async(TmpK, (long)Kt * N * P.d, s));
+      RETURN_IF(zero_async(dgain, 64, s));
+      for (int k = 0; k < Kt; ++k) {
+        const float* src = dWp + (size_t)slotOf[k] * IO;
+        GemmArgs q = gemm_args(EK + (size_t)k * N * P.d, src, ag.weights_pool + (size_t)k * IO, P.d, (int)IO, N);
+        q.sAm = 1; q.sAk = P.d; q.sBk = (long)S * IO; q.sBn = 1; q.sCm = (long)Kt * IO; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s));
+        GemmArgs e = gemm_args(src, ap.weights_pool + (size_t)k * IO, TmpK + (size_t)k * N * P.d, N, P.d, (int)IO);
+        e.sAm = (long)S * IO; e.sAk = 1; e.sBk = 1; e.sBn = (long)Kt * IO; e.sCm = P.d; e.sCn = 1;
+        e.mode = 1; e.split = 32;
+        RETURN_IF(gemm(e, 1, s));
+      }
+      hipLaunchKernelGGL(k_emb_grad, dim3(blocks_for((size_t)N * P.d), (unsigned)Kt), dim3(256), 0, s, TmpK, FK,
+                         prm->node_emb, wg, Kt, N, P.d, g->node_emb, dgain);
+      CHECK_LAUNCH();
+      if (D->scale_by_g) {
+        hipLaunchKernelGGL(k_softmax_bwd_small, dim3(1), dim3(64), 0, s, ap.weights_g, dgain, Kt, ag.weights_g);
+        CHECK_LAUNCH();
+      }
+      {  // bias = E . bias_pool
+        GemmArgs q = gemm_args(prm->node_emb, dBias, ag.bias_pool, P.d, O, N);
+        q.sAm = 1; q.sAk = P.d; q.sBk = O; q.sBn = 1; q.sCm = O; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s));
+        if (g->node_emb) {
+          GemmArgs e = gemm_args(dBias, ap.bias_pool, g->node_emb, N, P.d, O);
+          e.sAm = O; e.sAk = 1; e.sBk = 1; e.sBn = O; e.sCm = P.d; e.sCn = 1; e.beta = 1.f;
+          RETURN_IF(gemm(e, 1, s));
+        }
+      }
+    }
+
+  // ---- adaptive adjacency (MultiATGCN.py:80-83) ----
+  if (adp) {
+    const bool bi = D->adp_mode == MATGCN_ADP_BI;
+    const int rank = bi ? D->embed_dim : D->adj_rank;
+    float* dL = tr + R.oDL;
+    hipLaunchKernelGGL(k_adaptive_adj_bwd, dim3((unsigned)N), dim3(256), 0, s, bi ? prm->node_emb : prm->node_vec1,
+                       bi ? nullptr : prm->node_vec2, rank, bi ? 1 : 0, N, dT, dL);
+    CHECK_LAUNCH();
+    if (!bi) {
+      if (!g->node_vec1 || !g->node_vec2) return MATGCN_ERR_NULL;
+      GemmArgs q = gemm_args(dL, prm->node_vec2, g->node_vec1, N, rank, N);
+      q.sAm = N; q.sAk = 1; q.sBk = 1; q.sBn = N; q.sCm = rank; q.sCn = 1;
+      RETURN_IF(gemm(q, 1, s));
+      GemmArgs e = gemm_args(prm->node_vec1, dL, g->node_vec2, rank, N, N);
+      e.sAm = 1; e.sAk = rank; e.sBk = N; e.sBn = 1; e.sCm = N; e.sCn = 1;
+      RETURN_IF(gemm(e, 1, s));
+    } else if (g->node_emb) {
+      GemmArgs q = gemm_args(dL, prm->node_emb, g->node_emb, N, rank, N);
+      q.sAm = N; q.sAk = 1; q.sBk = rank; q.sBn = 1; q.sCm = rank; q.sCn = 1; q.beta = 1.f;
+      RETURN_IF(gemm(q, 1, s));
+      q.sAm = 1; q.sAk = N;   // transposed logits gradient
+      RETURN_IF(gemm(q, 1, s));
+    }
+  }
+  return MATGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes) {
+  if (!bytes) return MATGCN_ERR_NULL;
+  Plan P;
+  RETURN_IF(make_plan(dims, &P));
+  TrainPlan R;
+  RETURN_IF(make_train_plan(P, &R));
+  *bytes = (size_t)R.floats * sizeof(float);
+  return MATGCN_OK;
+}
+
+int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                         float* out, void* workspace, size_t workspace_bytes, void* train, size_t train_bytes,
+                         void* stream) {
+  if (!prepared || !X || !out || !train) return MATGCN_ERR_NULL;
+  Ctx c;
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
+  for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
+  RETURN_IF(check_layer_params(dims, params));
+  const Plan& P = c.P;
+  if (dims->cheb_k > 2 || P.gcnOff || P.headT != P.T) return MATGCN_ERR_UNSUPPORTED;
+  RETURN_IF(make_train_plan(P, &c.R));
+  if (train_bytes < (size_t)c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
+  c.train = (float*)train;
+  RETURN_IF(zero_async(c.train, c.R.savedFloats, c.s));   // rows of the padding nodes stay zero
+  float* x0p = c.ws + P.oX0p;
+  RETURN_IF(fuse_padded(c, X, x0p));
+  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+}
+
+int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                    const float* d_out, const matgcn_grads* grads, void* workspace, size_t workspace_bytes,
+                    void* train, size_t train_bytes, void* stream) {
+  if (!prepared || !X || !d_out || !grads || !train) return MATGCN_ERR_NULL;
+  Bwd b;
+  RETURN_IF(make_ctx(&b.c, dims, params, prepared, workspace, workspace_bytes, stream));
+  RETURN_IF(check_layer_params(dims, params));
+  RETURN_IF(make_train_plan(b.c.P, &b.c.R));
+  if (train_bytes < (size_t)b.c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
+  b.X = X; b.g = grads; b.tr = (float*)train;
+  return backward_impl(b, d_out);
+}
+
+int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* desc, float alpha, float beta,
+                      void* stream) {
+  if (!A || !B || !C || !desc) return MATGCN_ERR_NULL;
+  GemmArgs g = gemm_args(A, B, C, (int)desc[0], (int)desc[1], (int)desc[2]);
+  g.K2 = (int)desc[3];
+  g.sAm = desc[4]; g.sAk = desc[5]; g.sAk2 = desc[6];
+  g.sBk = desc[7]; g.sBn = desc[8]; g.sBk2 = desc[9];
+  g.sCm = desc[10]; g.sCn = desc[11];
+  const int nb1 = (int)desc[12];
+  g.nb2 = (int)desc[13];
+  g.bA1 = desc[14]; g.bA2 = desc[15]; g.bB1 = desc[16]; g.bB2 = desc[17]; g.bC1 = desc[18]; g.bC2 = desc[19];
+  g.mode = (int)desc[20]; g.split = (int)desc[21];
+  g.alpha = alpha; g.beta = beta;
+  if (g.nb2 < 1 || g.split < 1 || nb1 < 1 || g.mode < 0 || g.mode > 1) return MATGCN_ERR_BAD_ARG;
+  return gemm(g, nb1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// matgcn_bwd_kernels.hip - kernels of the backward pass: autograd of
+// MultiATGCN.forward (MultiATGCN.py:76-128,142-150,194-212,363-420) as explicit HIP kernels.
+//
+// Round-1 shape of the backward: correctness first.  Every contraction of the backward is an instance of ONE
+// strided, two-level-batched fp32 GEMM on the exact-fp32 matrix cores (k_bgemm, v_mfma_f32_16x16x4_f32, 64 x 64
+// tiles through LDS); the pointwise algebra of the two GRU cells, the blend, the softmaxes and the head fusion
+// lives in small element-wise kernels.  The schedule (matgcn_bwd.hip) keeps the time-sequential chain minimal -
+// only the recurrent (h) columns are back-propagated step by step - and batches everything else over all T steps:
+// the x columns, every weight gradient and the gradient of the adaptive adjacency.
+#ifndef MATGCN_BWD_KERNELS_HIP
+#define MATGCN_BWD_KERNELS_HIP
+
+// f32x4 / MFMA16 / sigmoid_f / cheb_scalar / StackMap come from matgcn_kernels.hip (same translation unit)
+
+// ---- generic strided batched GEMM ------------------------------------------------------------------------
+//   C[b1][b2][m][n] (+)= alpha * sum_{k2 < K2} sum_{k < K} A[b1][b2][m][k2][k] * B[b1][b2][k2][k][n]
+// element (m, k2, k) of A sits at A + b1*bA1 + b2*bA2 + m*sAm + k2*sAk2 + k*sAk (B, C alike): transposes, slices
+// and interleaved layouts are all strides.  mode 0: C = alpha*acc + beta*C; mode 1: atomicAdd(C, alpha*acc) with the
+// (k2, k) range additionally split over `split` workgroups (C must hold its initial value beforehand).
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K, K2;
+  long sAm, sAk, sAk2, sBk, sBn, sBk2, sCm, sCn;
+  int nb2;                       // inner batch count: blockIdx.z = (b1 * nb2 + b2) * split + part
+  long bA1, bA2, bB1, bB2, bC1, bC2;
+  float alpha, beta;
+  int mode, split;
+};
+
+#define BG_LD 80   // LDS row pitch (floats): lanes with kq = 0..3 land 16 banks apart
+
+__global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
+  __shared__ float As[2][16][BG_LD];
+  __shared__ float Bs[2][16][BG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  int z = blockIdx.z;
+  const int part = z % g.split;
+  z /= g.split;
+  const int b2 = z % g.nb2, b1 = z / g.nb2;
+  const float* A = g.A + (size_t)b1 * g.bA1 + (size_t)b2 * g.bA2;
+  const float* B = g.B + (size_t)b1 * g.bB1 + (size_t)b2 * g.bB2;
+  float* C = g.C + (size_t)b1 * g.bC1 + (size_t)b2 * g.bC2;
+  // element of the 64 x 16 A tile (16 x 64 B tile) this thread loads in sweep i: the unit-stride axis runs fastest
+  const bool aK = g.sAk == 1, bN = g.sBn == 1;
+  int am[4], ak[4], bk[4], bn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (aK) { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; } else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
+    if (bN) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
+  }
+  const int kTiles = (g.K + 15) >> 4;
+  const long total = (long)g.K2 * kTiles;              // K tiles over (k2, k)
+  const long per = (total + g.split - 1) / g.split;
+  const long tBeg = (long)part * per, tEnd = tBeg + per < total ? tBeg + per : total;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ra[4], rb[4];
+  auto fetch = [&](long tile) {
+    const int k2 = (int)(tile / kTiles), k0 = (int)(tile - (long)k2 * kTiles) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + am[i], k = k0 + ak[i];
+      ra[i] = (m < g.M && k < g.K) ? A[(size_t)m * g.sAm + (size_t)k2 * g.sAk2 + (size_t)k * g.sAk] : 0.f;
+      const int n = n0 + bn[i], kb = k0 + bk[i];
+      rb[i] = (n < g.N && kb < g.K) ? B[(size_t)kb * g.sBk + (size_t)k2 * g.sBk2 + (size_t)n * g.sBn] : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[buf][ak[i]][am[i]] = ra[i];
+      Bs[buf][bk[i]][bn[i]] = rb[i];
+    }
+  };
+  if (tBeg < tEnd) {
+    fetch(tBeg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (long tile = tBeg; tile < tEnd; ++tile) {
+      const bool more = tile + 1 < tEnd;
+      if (more) fetch(tile + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + kq;
+        float av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = As[buf][k][wm * 32 + a * 16 + j];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bv[b] = Bs[buf][k][wn * 32 + b * 16 + j];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a], bv[b], acc[a][b]);
+      }
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 32 + a * 16 + 4 * kq + e, n = n0 + wn * 32 + b * 16 + j;
+        if (m >= g.M || n >= g.N) continue;
+        float* dst = C + (size_t)m * g.sCm + (size_t)n * g.sCn;
+        const float v = g.alpha * acc[a][b][e];
+        if (g.mode == 1) unsafeAtomicAdd(dst, v);
+        else *dst = (g.beta != 0.f) ? v + g.beta * *dst : v;
+      }
+}
+
+// ---- plain (row-major) folded node-adaptive weights for the backward GEMMs ------------------------------------
+// Wp[n][s][i][o] = the weights the forward node kernels contract with, slot s = 0 (identity, with the diagonal
+// supports folded in) or a dense slot: g_k * sum_d E[n][d] Wpool[d][k][i][o]  (MultiATGCN.py:102-105; StackMap)
+struct PlainPrep {
+  const float* E;
+  const float* wpool;
+  const float* wg;       // weights_g or null
+  float* out;            // [N][S][I][O]
+  int d, I, O, N, S;
+  StackMap map;
+};
+
+__device__ __forceinline__ float stack_gain(const float* wg, int Kt, int k) {
+  if (!wg) return 1.f;
+  float mx = -3.0e38f, sum = 0.f;
+  for (int q = 0; q < Kt; ++q) mx = fmaxf(mx, wg[q]);
+  for (int q = 0; q < Kt; ++q) sum += expf(wg[q] - mx);
+  return expf(wg[k] - mx) / sum;
+}
+
+__global__ __launch_bounds__(256) void k_prep_plain(PlainPrep a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per = (size_t)a.S * a.I * a.O;
+  if (idx >= per) return;
+  const int n = blockIdx.y;
+  const int o = idx % a.O, i = (idx / a.O) % a.I, s = idx / ((size_t)a.O * a.I);
+  const size_t dstride = (size_t)a.map.KtotOrig * a.I * a.O;
+  const int k = a.map.keepK[s];
+  const float* e = a.E + (size_t)n * a.d;
+  float acc = 0.f;
+  for (int dd = 0; dd < a.d; ++dd) acc = fmaf(e[dd], a.wpool[dd * dstride + ((size_t)k * a.I + i) * a.O + o], acc);
+  acc *= stack_gain(a.wg, a.map.KtotOrig, k);
+  if (s == 0)
+    for (int q = 0; q < a.map.nDiag; ++q) {
+      const int kq2 = a.map.diagK[q];
+      float part = 0.f;
+      for (int dd = 0; dd < a.d; ++dd) part = fmaf(e[dd], a.wpool[dd * dstride + ((size_t)kq2 * a.I + i) * a.O + o], part);
+      const float t = cheb_scalar(a.map.diagSrc[q][(size_t)n * (a.map.N + 1)], a.map.diagOrder[q]);
+      acc = fmaf(t * stack_gain(a.wg, a.map.KtotOrig, kq2), part, acc);
+    }
+  a.out[(size_t)n * per + idx] = acc;
+}
+
+// EK[k][n][d] = g_k * f_k[n] * E[n][d], f_k = 1 for kept slots, the Chebyshev value of the diagonal otherwise;
+// FK[k][n] = f_k[n]  (left operands of the pool-gradient GEMMs)
+__global__ __launch_bounds__(256) void k_scaled_emb(const float* __restrict__ E, const float* __restrict__ wg,
+                                                    StackMap map, int d, float* __restrict__ EK,
+                                                    float* __restrict__ FK) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (idx >= map.N * d) return;
+  const int n = idx / d;
+  float f = 1.f;
+  for (int q = 0; q < map.nDiag; ++q)
+    if (map.diagK[q] == k) f = cheb_scalar(map.diagSrc[q][(size_t)n * (map.N + 1)], map.diagOrder[q]);
+  EK[(size_t)k * map.N * d + idx] = stack_gain(wg, map.KtotOrig, k) * f * E[idx];
+  if (idx % d == 0) FK[(size_t)k * map.N + n] = f;
+}
+
+// dE[n][d] += sum_k g_k f_k[n] TmpK[k][n][d];   dgain[k] += sum_{n,d} f_k[n] E[n][d] TmpK[k][n][d]
+__global__ __launch_bounds__(256) void k_emb_grad(const float* __restrict__ TmpK, const float* __restrict__ FK,
+                                                  const float* __restrict__ E, const float* __restrict__ wg, int Kt,
+                                                  int N, int d, float* __restrict__ dE, float* __restrict__ dgain) {
+  __shared__ float red[256];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  float part = 0.f;
+  if (idx < N * d) {
+    const int n = idx / d;
+    const float f = FK[(size_t)k * N + n], v = TmpK[(size_t)k * N * d + idx];
+    if (dE) unsafeAtomicAdd(&dE[idx], stack_gain(wg, Kt, k) * f * v);
+    part = f * E[idx] * v;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && dgain) unsafeAtomicAdd(&dgain[k], red[0]);
+}
+
+// softmax backward of a short vector: dw[k] = g_k * (dg[k] - sum_j g_j dg[j])   (weights_g, weight_tsg)
+__global__ void k_softmax_bwd_small(const float* __restrict__ w, const float* __restrict__ dg, int K,
+                                    float* __restrict__ dw) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float dot = 0.f;
+  for (int k = 0; k < K; ++k) dot += stack_gain(w, K, k) * dg[k];
+  for (int k = 0; k < K; ++k) dw[k] = stack_gain(w, K, k) * (dg[k] - dot);
+}
+
+// ---- adaptive adjacency backward (MultiATGCN.py:80-83): dA (N,N) -> gradient of the pre-relu logits ------------
+// one workgroup per row n: p = softmax(relu(l)); dl[m] = p[m] * (dA[n][m] - sum_j dA[n][j] p[j]) * (l[m] > 0)
+__global__ __launch_bounds__(256) void k_adaptive_adj_bwd(const float* __restrict__ e1, const float* __restrict__ e2,
+                                                          int rank, int bidir, int N, const float* __restrict__ dA,
+                                                          float* __restrict__ dL) {
+  __shared__ float red[256];
+  __shared__ float erow[64];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int r = tid; r < rank; r += 256) erow[r] = e1[(size_t)n * rank + r];
+  __syncthreads();
+  auto raw = [&](int m) {
+    float s = 0.f;
+    if (bidir) { for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e1[(size_t)m * rank + r], s); }
+    else { for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e2[(size_t)r * N + m], s); }
+    return s;
+  };
+  auto reduce = [&](float v, bool isMax) {
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] = isMax ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float mx = 0.f;
+  for (int m = tid; m < N; m += 256) mx = fmaxf(mx, fmaxf(raw(m), 0.f));
+  mx = reduce(mx, true);
+  float sum = 0.f;
+  for (int m = tid; m < N; m += 256) sum += expf(fmaxf(raw(m), 0.f) - mx);
+  const float inv = 1.0f / reduce(sum, false);
+  float dot = 0.f;
+  for (int m = tid; m < N; m += 256) dot += dA[(size_t)n * N + m] * expf(fmaxf(raw(m), 0.f) - mx) * inv;
+  dot = reduce(dot, false);
+  for (int m = tid; m < N; m += 256) {
+    const float l = raw(m);
+    const float p = expf(fmaxf(l, 0.f) - mx) * inv;
+    dL[(size_t)n * N + m] = l > 0.f ? p * (dA[(size_t)n * N + m] - dot) : 0.f;
+  }
+}
+
+// ---- element-wise pieces of the recurrent chain -------------------------------------------------------------
+// All state-like tensors are [B][Np][64] slabs ("S layout"); idx runs over B*Np*64.
+//
+// step (l, t), part 1: blend + residual cell output algebra (MultiATGCN.py:148-150, 205-208)
+//   h' = g ha + (1-g) res,  res = r2 ha + (1-r2) hc2,  ha = r h + (1-r) hc
+//   in : dhp = dSeq_l[t] (+ dcarry), saved z?,r,hc,z2,r2,hc2, h = h_{t-1}
+//   out: dHa (partial: blend + r2 paths), dpu2 = dhc2 * (1 - hc2^2), dr2 -> kept in DR2, blend-scalar gradient
+struct ChainArgs {
+  const float* dseq;     // dSeq_l[t]
+  const float* dcarry;   // dh carried from step t+1 (null at t = T-1)
+  const float* hprev;    // h_{t-1} (null at t = 0: zeros)
+  const float *z, *r, *hc, *z2, *r2, *hc2;
+  const float* blend;    // &weights_gru[l][t]
+  float* dblend;         // &dweights_gru[l][t]
+  float* dha;            // [B][Np][64]
+  float* dpu2;           // DPU2[t]  [B][Np][64]
+  float* dpg2;           // DPG2[t]  [B][Np][128]
+  float* dpu;            // DPU[t]   [B][Np][64]
+  float* dpg;            // DPG[t]   [B][Np][128]
+  const float* dzh2;     // [B][Np][64] gradient of z2*ha  (GEMM result)
+  const float* dzhA;     // dA buffer of the update AGCN [B][S][Np][64] (slot 0 = direct z*h gradient)
+  const float* dzhMix;   // transposed-mix result [B][Np][64] (null when Ks = 0)
+  const float* dhA;      // dA buffer of the gate AGCN
+  const float* dhMix;
+  float* dh;             // running dh_{t-1}: written by part 3, completed by part 4 (becomes the next carry)
+  float* dr;             // scratch [B][Np][64]
+  int B, N, Np, S;
+};
+
+__device__ __forceinline__ float ha_of(const ChainArgs& a, size_t idx) {
+  const float h = a.hprev ? a.hprev[idx] : 0.f, r = a.r[idx];
+  return r * h + (1.f - r) * a.hc[idx];
+}
+
+__global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
+  __shared__ float red[256];
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)a.B * a.Np * 64;
+  float part = 0.f;
+  if (idx < total) {
+    const int n = (idx >> 6) % a.Np;
+    const float dhp = a.dseq[idx] + (a.dcarry ? a.dcarry[idx] : 0.f);
+    const float g = sigmoid_f(a.blend[0]);
+    const float ha = ha_of(a, idx), r2 = a.r2[idx], hc2 = a.hc2[idx];
+    const float res = r2 * ha + (1.f - r2) * hc2;
+    if (n < a.N) part = dhp * (ha - res);
+    const float dres = (1.f - g) * dhp;
+    a.dha[idx] = g * dhp + dres * r2;
+    a.dpu2[idx] = dres * (1.f - r2) * (1.f - hc2 * hc2);
+    a.dr[idx] = dres * (ha - hc2);     // dr2, consumed by k_chain_res_gate
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float g = sigmoid_f(a.blend[0]);
+    unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
+  }
+}
+
+// part 2: gradient of z2*ha arrived -> dz2, dha += dzh2 * z2, gate pre-activation gradient of the residual cell
+__global__ __launch_bounds__(256) void k_chain_res_gate(ChainArgs a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.B * a.Np * 64) return;
+  const size_t row = idx >> 6;
+  const int o = idx & 63;
+  const float ha = ha_of(a, idx), z2 = a.z2[idx], r2 = a.r2[idx], dzh2 = a.dzh2[idx];
+  a.dha[idx] += dzh2 * z2;
+  a.dpg2[row * 128 + o] = dzh2 * ha * z2 * (1.f - z2);
+  a.dpg2[row * 128 + 64 + o] = a.dr[idx] * r2 * (1.f - r2);
+}
+
+// part 3: graph cell output algebra (MultiATGCN.py:127): ha = r h + (1-r) hc
+__global__ __launch_bounds__(256) void k_chain_cell_out(ChainArgs a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.B * a.Np * 64) return;
+  const float h = a.hprev ? a.hprev[idx] : 0.f, r = a.r[idx], hc = a.hc[idx], dha = a.dha[idx];
+  a.dr[idx] = dha * (h - hc);
+  a.dh[idx] = dha * r;
+  a.dpu[idx] = dha * (1.f - r) * (1.f - hc * hc);
+}
+
+// part 4: gradient of z*h arrived (slot 0 of the update AGCN's dA + transposed mix of its dense slots)
+__global__ __launch_bounds__(256) void k_chain_cell_gate(ChainArgs a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.B * a.Np * 64) return;
+  const size_t row = idx >> 6;
+  const int o = idx & 63;
+  const size_t b = row / a.Np, n = row - b * a.Np;
+  float dzh = a.dzhA[((b * a.S) * a.Np + n) * 64 + o];
+  if (a.dzhMix) dzh += a.dzhMix[idx];
+  const float h = a.hprev ? a.hprev[idx] : 0.f, z = a.z[idx], r = a.r[idx];
+  a.dh[idx] += dzh * z;
+  a.dpg[row * 128 + o] = dzh * h * z * (1.f - z);
+  a.dpg[row * 128 + 64 + o] = a.dr[idx] * r * (1.f - r);
+}
+
+// part 5: gradient of h from the gate AGCN arrived: dh_{t-1} complete
+__global__ __launch_bounds__(256) void k_chain_carry(ChainArgs a) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.B * a.Np * 64) return;
+  const size_t row = idx >> 6;
+  const int o = idx & 63;
+  const size_t b = row / a.Np, n = row - b * a.Np;
+  float v = a.dh[idx] + a.dhA[((b * a.S) * a.Np + n) * 64 + o];
+  if (a.dhMix) v += a.dhMix[idx];
+  a.dh[idx] = v;
+}
+
+// ---- small helpers -------------------------------------------------------------------------------------------
+// dst[r][n][c] += src[r][slot 0][n][c]   (src rows hold S slabs of Np*C)
+__global__ __launch_bounds__(256) void k_add_slot0(float* __restrict__ dst, const float* __restrict__ src, size_t rows,
+                                                   int Np, int C, int S) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per = (size_t)Np * C;
+  if (idx >= rows * per) return;
+  const size_t r = idx / per, q = idx - r * per;
+  dst[idx] += src[r * S * per + q];
+}
+
+// out[t][b][n][c] = a[t][b][n][c] * b[t][b][n][c]  (z * h_{t-1} for all steps)
+__global__ __launch_bounds__(256) void k_mul(const float* __restrict__ x, const float* __restrict__ y,
+                                             float* __restrict__ out, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < n) out[idx] = x[idx] * y[idx];
+}
+
+// ha = r h + (1-r) hc and z2*ha for all steps (inputs of the residual cell's weight gradients)
+__global__ __launch_bounds__(256) void k_ha_all(const float* __restrict__ r, const float* __restrict__ hprev,
+                                                const float* __restrict__ hc, const float* __restrict__ z2,
+                                                float* __restrict__ ha, float* __restrict__ z2ha, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const float v = r[idx] * hprev[idx] + (1.f - r[idx]) * hc[idx];
+  ha[idx] = v;
+  z2ha[idx] = z2[idx] * v;
+}
+
+// x0p [B][T][Np][C] (batch-major) -> time-major [T][B][Np][C]
+__global__ __launch_bounds__(256) void k_x0_time_major(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                       int T, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per = (size_t)Np * C;
+  if (idx >= (size_t)T * B * per) return;
+  const size_t q = idx % per;
+  const int b = (idx / per) % B;
+  const int t = idx / (per * B);
+  dst[idx] = src[((size_t)b * T + t) * per + q];
+}
+
+// column sums over the rows of a [rows][Np][O] tensor, per node: out[n][o] = sum_rows src[row][n][o]
+__global__ __launch_bounds__(256) void k_node_colsum(const float* __restrict__ src, size_t rows, int N, int Np, int O,
+                                                     float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * O) return;
+  const int n = idx / O, o = idx - n * O;
+  float s = 0.f;
+  for (size_t r = 0; r < rows; ++r) s += src[(r * Np + n) * O + o];
+  out[idx] = s;
+}
+
+// column sums over rows AND nodes: out[o] = sum_{row, n < N} src[row][n][o]   (nn.Linear bias gradients)
+__global__ __launch_bounds__(256) void k_colsum_all(const float* __restrict__ src, size_t rows, int N, int Np, int O,
+                                                    float* __restrict__ out) {
+  __shared__ float red[256];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  const size_t total = rows * N;
+  for (size_t q = threadIdx.x; q < total; q += 256) {
+    const size_t r = q / N, n = q - r * N;
+    s += src[(r * Np + n) * O + o];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[o] = red[0];
+}
+
+// ---- output head backward (MultiATGCN.py:416-418): dOut (B, out, N, od) -> plain [B][Np][CH] with oc = o*od + d
+__global__ __launch_bounds__(256) void k_dout_rows(const float* __restrict__ dout, float* __restrict__ dst, int B,
+                                                   int outSteps, int N, int Np, int od) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int CH = outSteps * od;
+  if (idx >= (size_t)B * Np * CH) return;
+  const int oc = idx % CH;
+  const int n = (idx / CH) % Np;
+  const size_t b = idx / ((size_t)CH * Np);
+  const int o = oc / od, d = oc - o * od;
+  dst[idx] = n < N ? dout[((b * outSteps + o) * N + n) * od + d] : 0.f;
+}
+
+// ---- head fusion backward (MultiATGCN.py:365-402) -----------------------------------------------------------------
+// dx0 time-major [T][B][Np][C0]; one thread per (head, t, n, c): reduces over the batch
+//   dweight_ts[h][t][n][c] = g_h * sum_b dx0 * X ;  dgain[h] += sum dx0 * X * weight_ts[h]
+struct FuseBwdArgs {
+  const float* X;
+  const float* dx0;
+  const float* tsg;
+  const float* ts[8];
+  float* dts[8];
+  float* dgain;          // [nTs] accumulators (zeroed by the caller)
+  int B, T, N, Np, C0, od, F, xSteps, startDim, nHeads, nTs;
+  int headBegin[8];
+};
+__global__ __launch_bounds__(256) void k_fuse_heads_bwd(FuseBwdArgs a) {
+  __shared__ float red[256];
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int h = blockIdx.y;
+  const size_t per = (size_t)a.T * a.N * a.od;
+  float gpart = 0.f;
+  if (idx < per) {
+    const int c = idx % a.od;
+    const int n = (idx / a.od) % a.N;
+    const int t = idx / ((size_t)a.od * a.N);
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      const float xv = a.X[(((size_t)b * a.xSteps + a.headBegin[h] + t) * a.N + n) * a.F + a.startDim + c];
+      s = fmaf(a.dx0[(((size_t)t * a.B + b) * a.Np + n) * a.C0 + c], xv, s);
+    }
+    a.dts[h][idx] = stack_gain(a.tsg, a.nTs, h) * s;
+    gpart = s * a.ts[h][idx];
+  }
+  red[threadIdx.x] = gpart;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) unsafeAtomicAdd(&a.dgain[h], red[0]);
+}
+
+#endif

@@ -16,6 +16,7 @@
 // single translation unit: the kernels are compiled together with their launchers
 #include "matgcn_kernels.hip"
 #include "matgcn_node16.hip"
+#include "matgcn_bwd_kernels.hip"
 
 namespace {
 
@@ -142,6 +143,58 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   return MATGCN_OK;
 }
 
+// ---- training buffer: activations saved by matgcn_forward_train + scratch of matgcn_backward -------------
+struct TrainPlan {
+  int S;                                   // slots the node GEMMs see: identity + dense
+  // saved per layer, each [T][B][Np][64]
+  long oZ[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS], oHC[MATGCN_MAX_LAYERS];
+  long oZ2[MATGCN_MAX_LAYERS], oR2[MATGCN_MAX_LAYERS], oHC2[MATGCN_MAX_LAYERS];
+  long savedFloats;                        // [0, savedFloats) is zeroed by forward_train, the rest by backward
+  long oWp[MATGCN_MAX_LAYERS][2], oDWp[MATGCN_MAX_LAYERS][2], oDBias[MATGCN_MAX_LAYERS][2];
+  long oDPU, oDPG, oDPU2, oDPG2;           // pre-activation gradients of every step
+  long oDSeq[2];                           // gradient of a layer's output sequence (ping-pong)
+  long oDAg, oDAu;                         // [T][B][S][Np][64] gradient of [s | mix(s)] of both AGCNs, h columns
+  long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
+  long oX0tm, oHprev, oZH, oHA, oZ2HA, oGall, oDAx, oDX0;
+  long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
+  long floats;
+};
+
+int make_train_plan(const Plan& P, TrainPlan* R) {
+  memset(R, 0, sizeof(*R));
+  R->S = P.Ktot;
+  long o = 0;
+  auto take = [&](long n) { long at = o; o += rup(n, 64); return at; };
+  const long slab = (long)P.B * P.Np * H, seq = slab * P.T;
+  for (int l = 0; l < P.L; ++l) {
+    R->oZ[l] = take(seq); R->oR[l] = take(seq); R->oHC[l] = take(seq);
+    R->oZ2[l] = take(seq); R->oR2[l] = take(seq); R->oHC2[l] = take(seq);
+  }
+  R->savedFloats = o;
+  for (int l = 0; l < P.L; ++l)
+    for (int part = 0; part < 2; ++part) {
+      const long O = part == 0 ? 128 : 64, I = P.Cl[l] + H;
+      R->oWp[l][part] = take((long)P.N * R->S * I * O);
+      R->oDWp[l][part] = take((long)P.N * R->S * I * O);
+      R->oDBias[l][part] = take((long)P.N * O);
+    }
+  R->oDPU = take(seq); R->oDPG = take(2 * seq); R->oDPU2 = take(seq); R->oDPG2 = take(2 * seq);
+  R->oDSeq[0] = take(seq); R->oDSeq[1] = take(seq);
+  R->oDAg = take(seq * R->S); R->oDAu = take(seq * R->S);
+  R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab); R->oMixOut = take(slab);
+  R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
+  R->oHprev = take(seq); R->oZH = take(seq); R->oHA = take(seq); R->oZ2HA = take(seq);
+  R->oGall = take(seq * (P.Ks > 0 ? P.Ks : 1));
+  R->oDAx = take(seq * R->S);
+  R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
+  R->oDT = take((long)P.N * P.N); R->oDL = take((long)P.N * P.N);
+  R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
+  R->oTmpK = take((long)P.KtotOrig * P.N * P.d); R->oDGain = take(64);
+  R->oDOutRows = take((long)P.B * P.Np * P.CH);
+  R->floats = o;
+  return MATGCN_OK;
+}
+
 // ---- optional in-situ launch timing (matgcn_profile_*) ------------------------------------------------
 struct Prof {
   int mask = 0, cap = 0, used = 0;
@@ -257,6 +310,8 @@ struct Ctx {
   const float* prep;
   float* ws;
   hipStream_t s;
+  float* train = nullptr;     // matgcn_forward_train: the training buffer (activations are saved into it)
+  TrainPlan R;
 };
 
 // dynamic LDS above 64 KB must be opted into once per kernel
@@ -264,10 +319,12 @@ int node_kernels_ready(int ldsBytes) {
   static int ready = 0;
   if (ready >= ldsBytes) return MATGCN_OK;
   const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -333,10 +390,17 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
   else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.B * 192;
   const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
+  const bool save = c.train != nullptr && res != nullptr;
+  if (save) {
+    const size_t at = (size_t)t * P.B * P.Np * H;
+    a.svZ = c.train + c.R.oZ[l] + at; a.svR = c.train + c.R.oR[l] + at; a.svHC = c.train + c.R.oHC[l] + at;
+    a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
+  }
   if (phase == 1) {
     a.s = Hx; a.w = c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    hipLaunchKernelGGL(k_gate16, grid, dim3(512), P.nodeLds, s, a);
+    if (save) hipLaunchKernelGGL(k_gate16<true>, grid, dim3(512), P.nodeLds, s, a);
+    else hipLaunchKernelGGL(k_gate16<false>, grid, dim3(512), P.nodeLds, s, a);
     return launch_ok();
   }
   a.s = ZHx; a.w = c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
@@ -345,9 +409,10 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    hipLaunchKernelGGL(k_update16<1>, grid, dim3(512), P.nodeLds, s, a);
+    if (save) hipLaunchKernelGGL((k_update16<1, true>), grid, dim3(512), P.nodeLds, s, a);
+    else hipLaunchKernelGGL((k_update16<1, false>), grid, dim3(512), P.nodeLds, s, a);
   } else {
-    hipLaunchKernelGGL(k_update16<0>, grid, dim3(512), P.nodeLds, s, a);
+    hipLaunchKernelGGL((k_update16<0, false>), grid, dim3(512), P.nodeLds, s, a);
   }
   return launch_ok();
 }
@@ -372,7 +437,7 @@ int res_step(const Ctx& c, int l, const float* xt, long xRowStride) {
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, &a);
   ProfScope prof(MATGCN_PROF_RES, c.s);
-  hipLaunchKernelGGL(k_update16<2>, dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, c.s, a);
+  hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, c.s, a);
   return launch_ok();
 }
 
@@ -424,7 +489,7 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
         else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
         {
           ProfScope prof(MATGCN_PROF_RES, cs);
-          hipLaunchKernelGGL(k_update16<2>, dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, cs, a);
+          hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, cs, a);
         }
         CHECK_LAUNCH();
         if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
@@ -918,3 +983,5 @@ int matgcn_profile_collect(float* ms, int* kinds, int capacity, int* count) {
 }
 
 }  // extern "C"
+
+#include "matgcn_bwd.hip"

@@ -55,6 +55,8 @@ struct Node16Args {
   const float* blend;    // &weights_gru[l][t] or null
   float* seq;            // Seq_l[:, t] or null: seq[b*seqRowStride + n*64 + o]
   long seqRowStride;
+  // training (SAVE instantiations): activations of this step kept for the backward, each [rows][Np][64]
+  float *svZ, *svR, *svHC, *svZ2, *svR2, *svHC2;
 };
 
 __device__ __forceinline__ float sigmoid16(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -168,6 +170,7 @@ __device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase
 }
 
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
+template <bool SAVE>
 __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;               // [64][16 slots]
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
       const float v = acc[rt][e];
       if (a.raw && b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
       const float sg = sigmoid16(v);
+      if (SAVE && b < a.rows) ((w < 4) ? a.svZ : a.svR)[((size_t)b * a.Np + n) * 64 + (o & 63)] = sg;
       Out[swz(lb, o, 32)] = (w < 4) ? sg * Hs[swz(lb, o, 16)] : sg;
     }
   }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
 // pairs so that every weight fragment is still fetched exactly once; the halves meet in LDS.  The residual cell
 // then runs two small GEMMs on tiles that never leave LDS.  Every global operand of a later phase is requested
 // before the barrier of the phase in front of it, so its latency hides under that phase.
-template <int MODE>
+template <int MODE, bool SAVE>
 __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;               // [64][16 slots]: z*h during the update GEMM, then h'
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
           const float hc = tanhf(acc[rt][e] + p[e] + pxv[rt][e]);
           const float rr = rv[rt][e];
           float hn = rr * hv[rt][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
+          if (SAVE && b < a.rows) a.svHC[((size_t)b * a.Np + n) * 64 + o4] = hc;
           if (b >= a.rows) hn = 0.f;
           if (MODE == 0) { if (b < a.rows) a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn; }
           else Hs[swz(lb, o4, 16)] = hn;                  // h' tile for the residual cell (z*h no longer needed)
@@ -528,6 +533,8 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
       for (int e = 0; e < 4; ++e) {
         const int lb = rt * 16 + 4 * kq + e;
         const float sg = sigmoid16(acc1[rt][e] + bg);
+        if (SAVE && rowBase + lb < a.rows)
+          ((w < 4) ? a.svZ2 : a.svR2)[((size_t)(rowBase + lb) * a.Np + n) * 64 + (o & 63)] = sg;
         if (w < 4) ZH2[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
         else R2[swz(lb, o - 64, 16)] = sg;
       }
@@ -567,6 +574,7 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
     for (int e = 0; e < 4; ++e) {
       const int lb = (2 * rp + q) * 16 + 4 * kq + e;
       const float hc = tanhf(acc2[q][e] + bu);
+      if (SAVE && rowBase + lb < a.rows) a.svHC2[((size_t)(rowBase + lb) * a.Np + n) * 64 + o4] = hc;
       const float hp = Hs[swz(lb, o4, 16)];
       const float rr = R2[swz(lb, o4, 16)];
       const float res = rr * hp + (1.0f - rr) * hc;

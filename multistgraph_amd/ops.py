@@ -143,6 +143,15 @@ def _check_tensor(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
     return t.contiguous()
 
 
+def debug_gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, desc, alpha=1.0, beta=0.0) -> None:
+    """matgcn_debug_gemm on raw buffers (tests): desc = the 22 integers of include/matgcn.h."""
+    lib = _lib.load()
+    arr = (C.c_int64 * 22)(*[int(v) for v in desc])
+    stream = C.c_void_p(torch.cuda.current_stream(c.device).cuda_stream)
+    _lib.check(lib.matgcn_debug_gemm(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr()), arr,
+                                     C.c_float(alpha), C.c_float(beta), stream), "matgcn_debug_gemm")
+
+
 def masked_mae_device(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
                       null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
     """(1 + out,) tensor [masked-MAE over all horizons, MAE@1 .. MAE@out] computed on the device by
@@ -261,6 +270,78 @@ class HotPath:
                                            C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
                                            C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward")
         return out
+
+    # ---- training step ---------------------------------------------------
+    def _train_buffer(self) -> torch.Tensor:
+        if getattr(self, "_train", None) is None:
+            nbytes = C.c_size_t()
+            _lib.check(self.lib.matgcn_train_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_train_bytes")
+            self._train = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        return self._train
+
+    def forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        """matgcn_forward that keeps the activations the backward needs (in the train buffer and the workspace)."""
+        s = self.spec
+        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        self._need_prepared()
+        tr = self._train_buffer()
+        out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_forward_train(C.byref(self.dims), C.byref(self.params),
+                                                 C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), ws, wsb, C.c_void_p(tr.data_ptr()),
+                                                 C.c_size_t(tr.numel() * 4), self._stream()), "matgcn_forward_train")
+        return out
+
+    def backward(self, x: torch.Tensor, d_out: torch.Tensor, state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Gradients of every tensor of `state` (the dict bind() saw) that the loss depends on, keyed by the same
+        names; must directly follow the matching forward_train (same workspace, same train buffer)."""
+        s = self.spec
+        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        d_out = _check_tensor(d_out, "d_out", (self.batch, s.out_window, s.nodes, s.out_dim))
+        grads: Dict[str, torch.Tensor] = {}
+        g = _lib.Params()
+
+        def new(name):
+            t = torch.empty_like(state[name], memory_format=torch.contiguous_format)
+            grads[name] = t
+            return t.data_ptr()
+
+        if state["node_emb"].requires_grad or not isinstance(state["node_emb"], torch.nn.Parameter):
+            g.node_emb = new("node_emb")
+        if s.adpadj == "unidirection":
+            g.node_vec1, g.node_vec2 = new("node_vec1"), new("node_vec2")
+        g.weight_tsg = new("weight_tsg")
+        for i in range(len(s.head_begin)):
+            g.weight_ts[i] = new("weight_ts.%d" % i)
+        g.weights_gru = new("encoder.weights_gru")
+        for l in range(s.layers):
+            for nm, dst in (("gate", g.gate), ("update", g.update)):
+                pre = "encoder.agru_cells.%d.%s." % (l, nm)
+                dst[l].weights_g = new(pre + "weights_g")
+                dst[l].weights_pool = new(pre + "weights_pool")
+                dst[l].bias_pool = new(pre + "bias_pool")
+            for nm, dst in (("gate", g.res_gate), ("update", g.res_update)):
+                pre = "encoder.res_cells.%d.%s." % (l, nm)
+                dst[l].weight = new(pre + "weight")
+                dst[l].bias = new(pre + "bias")
+        g.end_conv_weight = new("end_conv.weight")
+        g.end_conv_bias = new("end_conv.bias")
+        if not s.scale_by_g:      # the stack is not scaled: weights_g does not reach the output
+            for l in range(s.layers):
+                for nm in ("gate", "update"):
+                    grads["encoder.agru_cells.%d.%s.weights_g" % (l, nm)].zero_()
+        for name, t in state.items():    # tensors the forward never reads (unused heads, node_vec* without
+            if name not in grads and (t.requires_grad or not isinstance(t, torch.nn.Parameter)):   # adaptive adjacency)
+                grads[name] = torch.zeros_like(t)
+        tr = self._train_buffer()
+        ws, wsb = self._ws()
+        _lib.check(self.lib.matgcn_backward(C.byref(self.dims), C.byref(self.params),
+                                            C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(d_out.data_ptr()), C.byref(g), ws, wsb,
+                                            C.c_void_p(tr.data_ptr()), C.c_size_t(tr.numel() * 4), self._stream()),
+                   "matgcn_backward")
+        return grads
 
     def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps) -> torch.Tensor:
         """Forward fed from the device-resident series (T, N, F): sample b's window rows are gathered by the

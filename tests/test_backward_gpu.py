@@ -1,0 +1,152 @@
+"""Training step: matgcn_forward_train + matgcn_backward vs torch autograd
+through the CPU oracle (oracle/matgcn_oracle.py, itself pinned to the reference's golden vectors; the
+gradient fixtures tests/golden/grad_*.npz come from autograd through the reference model itself).
+
+Tolerance: 1e-4 max-normalised per parameter tensor (fp32; the oracle side runs in fp64).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_DIR, TINY, Case, max_norm_err
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 1e-4
+C2 = [n for n in TINY if n.endswith("_c2") or n.endswith("dyn7") or n.endswith("out12")]
+
+
+def _path(c, fold=True):
+    from multistgraph_amd.ops import HotPath, diagonal_mask, spec_from_config
+    dev = torch.device("cuda:0")
+    use_static = c.adpadj == "none" or c.adjtype == "multi"
+    st = torch.from_numpy(c.gold["static_supports"]).to(dev) if use_static else None
+    spec = spec_from_config(c.config(), c.data_feature, c.n, min(c.n, 20), st.shape[0] if use_static else 0,
+                            diagonal_mask(st) if fold else 0)
+    hp = HotPath(spec, c.b, dev)
+    state = {k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}
+    hp.bind(state, st)
+    return hp, dev, state
+
+
+def _oracle_grads(c, d_out):
+    """d(sum(out * d_out))/d(param) by autograd through the oracle in fp64."""
+    from oracle import matgcn_oracle as orc
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in c.state.items()}
+    use_static = c.adpadj == "none" or c.adjtype == "multi"
+    statics = orc.supports_as_tensors(c.gold["static_supports"], torch.float64) if use_static else []
+    y = orc.forward(torch.tensor(c.x, dtype=torch.float64), p, statics, c.oracle_cfg(), faithful=False)
+    (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
+    return y.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in p.items()}
+
+
+def _reference_gemm(a, b, c, desc, alpha, beta):
+    (M, N, K, K2, sAm, sAk, sAk2, sBk, sBn, sBk2, sCm, sCn, nb1, nb2, bA1, bA2, bB1, bB2, bC1, bC2, mode, split) = desc
+    out = c.astype(np.float64).copy()
+    m, n, k, k2 = np.arange(M), np.arange(N), np.arange(K), np.arange(K2)
+    for b1 in range(nb1):
+        for b2 in range(nb2):
+            ia = b1 * bA1 + b2 * bA2 + m[:, None, None] * sAm + k2[None, :, None] * sAk2 + k[None, None, :] * sAk
+            ib = b1 * bB1 + b2 * bB2 + k2[:, None, None] * sBk2 + k[None, :, None] * sBk + n[None, None, :] * sBn
+            acc = np.einsum("mqk,qkn->mn", a[ia].astype(np.float64), b[ib].astype(np.float64))
+            ic = b1 * bC1 + b2 * bC2 + m[:, None] * sCm + n[None, :] * sCn
+            out[ic] = alpha * acc + (out[ic] if mode == 1 else beta * out[ic])
+    return out
+
+
+@pytest.mark.parametrize("case", [
+    # M, N, K, K2, sAm, sAk, sAk2, sBk, sBn, sBk2, sCm, sCn, nb1, nb2, bA1.., mode, split
+    dict(M=70, N=33, K=45, K2=1, ta=False, tb=False, nb1=1, nb2=1, mode=0, split=1, beta=0.0),
+    dict(M=64, N=64, K=16, K2=1, ta=True, tb=True, nb1=3, nb2=2, mode=0, split=1, beta=0.5),
+    dict(M=5, N=130, K=7, K2=6, ta=True, tb=False, nb1=2, nb2=1, mode=0, split=1, beta=1.0),
+    dict(M=100, N=20, K=37, K2=9, ta=False, tb=True, nb1=1, nb2=3, mode=1, split=5, beta=0.0),
+    dict(M=1, N=1, K=1, K2=1, ta=False, tb=False, nb1=1, nb2=1, mode=1, split=3, beta=0.0),
+])
+def test_strided_batched_gemm(case, lib_built):
+    from multistgraph_amd.ops import debug_gemm
+    rng = np.random.default_rng(7)
+    M, N, K, K2, nb1, nb2 = (case[k] for k in ("M", "N", "K", "K2", "nb1", "nb2"))
+    # A element (m, k2, k) and B element (k2, k, n) inside padded per-batch blocks; ta/tb swap the fast axis
+    if case["ta"]:
+        sAk, sAm = M + 3, 1
+    else:
+        sAm, sAk = K + 2, 1
+    sAk2 = (M + 3) * (K + 2)
+    blockA = sAk2 * K2 + 5
+    if case["tb"]:
+        sBn, sBk = K + 1, 1
+    else:
+        sBk, sBn = N + 4, 1
+    sBk2 = (K + 1) * (N + 4)
+    blockB = sBk2 * K2 + 3
+    sCm, sCn = N + 2, 1
+    blockC = M * sCm + 1
+    bA2, bA1 = blockA, blockA * nb2
+    bB2, bB1 = blockB, blockB * nb2
+    bC2, bC1 = blockC, blockC * nb2
+    a = rng.standard_normal(blockA * nb1 * nb2).astype(np.float32)
+    b = rng.standard_normal(blockB * nb1 * nb2).astype(np.float32)
+    c0 = rng.standard_normal(blockC * nb1 * nb2).astype(np.float32)
+    desc = (M, N, K, K2, sAm, sAk, sAk2, sBk, sBn, sBk2, sCm, sCn, nb1, nb2, bA1, bA2, bB1, bB2, bC1, bC2,
+            case["mode"], case["split"])
+    dev = torch.device("cuda:0")
+    ta, tb, tc = (torch.from_numpy(v).to(dev) for v in (a, b, c0))
+    debug_gemm(ta, tb, tc, desc, alpha=1.25, beta=case["beta"])
+    want = _reference_gemm(a, b, c0, desc, 1.25, case["beta"])
+    assert max_norm_err(tc.cpu().numpy(), want) <= 2e-6
+
+
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("name", C2)
+def test_backward_matches_oracle_autograd(name, fold, lib_built):
+    c = Case(name)
+    if not fold and c.adjtype not in ("multi", "cosine", "identity"):
+        pytest.skip("no diagonal support to fold in this mode")
+    hp, dev, state = _path(c, fold)
+    rng = np.random.default_rng(c.seed + 11)
+    d_out = rng.standard_normal((c.b, c.out, c.n, 1)).astype(np.float32)
+    want_y, want = _oracle_grads(c, d_out)
+    x = torch.from_numpy(c.x).to(dev)
+    y = hp.forward_train(x)
+    assert max_norm_err(y.cpu().numpy(), want_y) <= 1e-4
+    assert torch.equal(y, hp.forward(x))                       # the saving instantiations compute the same forward
+    hp.forward_train(x)
+    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state)
+    torch.cuda.synchronize()
+    assert set(grads) == set(want)
+    worst = {}
+    for k, g in grads.items():
+        w = want[k]
+        if np.abs(w).max() == 0.0:
+            assert float(g.abs().max()) <= 1e-6, k
+            continue
+        worst[k] = max_norm_err(g.cpu().numpy(), w)
+    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("grad_")))
+def test_backward_matches_reference_autograd(name, lib_built):
+    """gradients of the reference's own calculate_loss(batch).backward() (tests/golden/make_golden.py)"""
+    c = Case(name)
+    gold = np.load(os.path.join(GOLDEN_DIR, "grad_%s.npz" % name))
+    hp, dev, state = _path(c)
+    x = torch.from_numpy(c.x).to(dev)
+    hp.forward_train(x)
+    grads = hp.backward(x, torch.from_numpy(gold["d_out"]).to(dev), state)
+    for k, g in grads.items():
+        w = gold["grad." + k]
+        if np.abs(w).max() == 0.0:
+            assert float(g.abs().max()) <= 1e-6, k
+        else:
+            assert max_norm_err(g.cpu().numpy(), w) <= GRAD_TOL, k
+
+
+def test_training_refuses_unbuilt_configurations(lib_built):
+    from multistgraph_amd import _lib
+    c = Case("tiny_multi_uni_c3")
+    hp, dev, _ = _path(c)
+    with pytest.raises(_lib.MatgcnError):
+        hp.forward_train(torch.from_numpy(c.x).to(dev))

@@ -10,7 +10,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #include "matgcn_node16.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-// pure weight-stream probes: same launch geometry as k_gate16, no LDS, no MFMA
+// pure weight-stream probes: same launch geometry as k_gate16<false>, no LDS, no MFMA
 template <int PATTERN>
 __global__ __launch_bounds__(512) void k_stream(const float* __restrict__ w, float* __restrict__ out, int nG) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -137,11 +137,11 @@ int main(int argc, char** argv) {
   float* Wg2 = dalloc((size_t)N * nG * 16 * 128, 0.01f);
   const int lds = (64 * 64 + 64 * 64 * 4) * 4;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int nb = 0;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gate16, 512, lds));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gate16<false>, 512, lds));
   printf("occupancy query: k_gate16 %d blocks/CU at %d B LDS\n", nb, lds);
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_update16<1>, 512, lds));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_update16<1, false>, 512, lds));
   printf("occupancy query: k_update16<1> %d blocks/CU\n", nb);
   Node16Args a; memset(&a, 0, sizeof(a));
   a.s = S; a.g = G; a.w = Wg; a.px = PX; a.rows = B; a.N = N; a.Np = Np; a.Ks = Ks; a.zh = ZH; a.r = R;
@@ -160,8 +160,8 @@ int main(int argc, char** argv) {
   const double fg = 2.0 * B * N * 320.0 * 128, fu = 2.0 * B * N * 320.0 * 64 + 2.0 * B * N * 128.0 * 192;
   if (argc > 1) {   // profiling mode: a few launches of one kernel
     for (int i = 0; i < 5; ++i) {
-      if (argv[1][0] == 'g') hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a);
-      else hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u);
+      if (argv[1][0] == 'g') hipLaunchKernelGGL(k_gate16<false>, dim3(N), dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((k_update16<1, false>), dim3(N), dim3(512), lds, s, u);
     }
     CK(hipStreamSynchronize(s));
     return 0;
@@ -191,10 +191,10 @@ int main(int argc, char** argv) {
     timeit("probe 1 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<1>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
     timeit("probe 0 x2 blocks/CU", 2 * fp, [&](int) { hipLaunchKernelGGL(k_probe<0>, dim3(512), dim3(512), lds, s, Wg, ZH, 24, 4); });
   }
-  timeit("gate16 (same W every launch)", fg, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, a); });
-  timeit("gate16 (alternating W sets)", fg, [&](int i) { Node16Args b2 = a; b2.w = (i & 1) ? Wg2 : Wg; hipLaunchKernelGGL(k_gate16, dim3(N), dim3(512), lds, s, b2); });
-  timeit("update16<1> (update+res)", fu, [&](int) { hipLaunchKernelGGL(k_update16<1>, dim3(N), dim3(512), lds, s, u); });
-  timeit("update16<0> (update only)", fu, [&](int) { hipLaunchKernelGGL(k_update16<0>, dim3(N), dim3(512), lds, s, u); });
+  timeit("gate16 (same W every launch)", fg, [&](int) { hipLaunchKernelGGL(k_gate16<false>, dim3(N), dim3(512), lds, s, a); });
+  timeit("gate16 (alternating W sets)", fg, [&](int i) { Node16Args b2 = a; b2.w = (i & 1) ? Wg2 : Wg; hipLaunchKernelGGL(k_gate16<false>, dim3(N), dim3(512), lds, s, b2); });
+  timeit("update16<1> (update+res)", fu, [&](int) { hipLaunchKernelGGL((k_update16<1, false>), dim3(N), dim3(512), lds, s, u); });
+  timeit("update16<0> (update only)", fu, [&](int) { hipLaunchKernelGGL((k_update16<0, false>), dim3(N), dim3(512), lds, s, u); });
   {
     const int rows = 4 * B, RB = rows / 64;
     float* X4 = dalloc((size_t)rows * Np * 64, 0.1f);
@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     timeit("px16 (4-step chunk)", 2.0 * rows * N * 320.0 * 192, [&](int) { hipLaunchKernelGGL(k_px16, dim3(((N + 7) / 8) * 8 * RB), dim3(512), lds, s, p); });
   }
-  { Node16Args b2 = a; b2.N = 256; timeit("gate16 256 nodes only", fg * 256 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(256), dim3(512), lds, s, b2); }); }
-  { Node16Args b2 = a; timeit("gate16 128 nodes only", fg * 128 / N, [&](int) { hipLaunchKernelGGL(k_gate16, dim3(128), dim3(512), lds, s, b2); }); }
+  { Node16Args b2 = a; b2.N = 256; timeit("gate16 256 nodes only", fg * 256 / N, [&](int) { hipLaunchKernelGGL(k_gate16<false>, dim3(256), dim3(512), lds, s, b2); }); }
+  { Node16Args b2 = a; timeit("gate16 128 nodes only", fg * 128 / N, [&](int) { hipLaunchKernelGGL(k_gate16<false>, dim3(128), dim3(512), lds, s, b2); }); }
   return 0;
 }
