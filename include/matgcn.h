@@ -202,6 +202,9 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
  * scratch.  matgcn_backward must see the SAME workspace and train buffers, untouched, that the matching
  * matgcn_forward_train call used (the sequences of every layer live in the workspace).
  * d_out (B, output_window, N, output_dim) is the gradient of the loss w.r.t. the forward's output.
+ * drop_mask: NULL (eval-mode forward), or the training-mode dropout in front of end_conv (MultiATGCN.py:416,
+ * F.dropout p = 0.1) as a (B, T, N, H) device tensor of multipliers 0 or 1/(1-p) drawn by the caller's RNG
+ * (torch: F.dropout(torch.ones(B,T,N,H))); the same mask goes to the matching matgcn_backward.
  * Reductions that meet in one address use fp32 atomics: gradients are reproducible to rounding, not bitwise.
  * Not built yet for training (MATGCN_ERR_UNSUPPORTED): cheb_order > 2, gcn_off, fnn_off. */
 typedef struct matgcn_agcn_grads {
@@ -233,11 +236,11 @@ typedef struct matgcn_grads {
 
 int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes);
 int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
-                         const float* X, float* out, void* workspace, size_t workspace_bytes, void* train,
-                         size_t train_bytes, void* stream);
+                         const float* X, const float* drop_mask, float* out, void* workspace,
+                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream);
 int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                    const float* d_out, const matgcn_grads* grads, void* workspace, size_t workspace_bytes,
-                    void* train, size_t train_bytes, void* stream);
+                    const float* drop_mask, const float* d_out, const matgcn_grads* grads, void* workspace,
+                    size_t workspace_bytes, void* train, size_t train_bytes, void* stream);
 
 /* The one contraction kernel of the backward, exposed for its parity test: a strided, two-level-batched fp32
  * GEMM  C[b1][b2] (+)= alpha * sum_{k2,k} A[b1][b2][m][k2][k] B[b1][b2][k2][k][n].  desc (22 x int64, host):

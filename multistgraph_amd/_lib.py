@@ -79,10 +79,10 @@ _SIGNATURES = {
     "matgcn_masked_mae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "matgcn_train_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
-    "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P,
+    "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, C.c_size_t, _P,
                                        C.c_size_t, _P]),
     # matgcn_grads has the layout of matgcn_params (non-const pointers): the same ctypes struct serves both
-    "matgcn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.POINTER(Params), _P,
+    "matgcn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.POINTER(Params), _P,
                                   C.c_size_t, _P, C.c_size_t, _P]),
     "matgcn_debug_gemm": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_float, C.c_float, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),

@@ -36,6 +36,7 @@ int gemm(const GemmArgs& g, int nb1, hipStream_t s) {
 struct Bwd {
   Ctx c;
   const float* X;
+  const float* dropMask;
   const matgcn_grads* g;
   float* tr;
 };
@@ -198,7 +199,7 @@ int backward_impl(Bwd& b, const float* dOut) {
   hipLaunchKernelGGL(k_colsum_all, dim3((unsigned)P.CH), dim3(256), 0, s, dOutRows, (size_t)B, N, Np, P.CH,
                      g->end_conv_bias);
   CHECK_LAUNCH();
-  const float* seqTop = c.ws + P.oSeq[P.L - 1];
+  const float* seqTop = b.dropMask ? tr + R.oSeqDrop : c.ws + P.oSeq[P.L - 1];   // what the head convolved
   float* dSeq = tr + R.oDSeq[0];
   {
     GemmArgs q = gemm_args(dOutRows, prm->end_conv_weight, dSeq, N, H, P.CH);
@@ -215,6 +216,11 @@ int backward_impl(Bwd& b, const float* dOut) {
     w.sCm = (long)T * H; w.sCn = 1; w.bC1 = H;
     w.mode = 1; w.split = 16;
     RETURN_IF(gemm(w, T, s));
+    if (b.dropMask) {
+      hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)T * slab)), dim3(256), 0, s, dSeq, b.dropMask, dSeq, B, T,
+                         N, Np);
+      CHECK_LAUNCH();
+    }
   }
 
   float* dT = tr + R.oDT;
@@ -458,8 +464,8 @@ int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes) {
 }
 
 int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                         float* out, void* workspace, size_t workspace_bytes, void* train, size_t train_bytes,
-                         void* stream) {
+                         const float* drop_mask, float* out, void* workspace, size_t workspace_bytes, void* train,
+                         size_t train_bytes, void* stream) {
   if (!prepared || !X || !out || !train) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
@@ -475,19 +481,27 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
-  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+  const float* seqTop = c.ws + P.oSeq[P.L - 1];
+  if (drop_mask) {
+    float* dropped = c.train + c.R.oSeqDrop;
+    hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)P.T * P.B * P.Np * H)), dim3(256), 0, c.s, seqTop,
+                       drop_mask, dropped, P.B, P.T, P.N, P.Np);
+    CHECK_LAUNCH();
+    seqTop = dropped;
+  }
+  return head_padded(c, seqTop, out);
 }
 
 int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                    const float* d_out, const matgcn_grads* grads, void* workspace, size_t workspace_bytes,
-                    void* train, size_t train_bytes, void* stream) {
+                    const float* drop_mask, const float* d_out, const matgcn_grads* grads, void* workspace,
+                    size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
   if (!prepared || !X || !d_out || !grads || !train) return MATGCN_ERR_NULL;
   Bwd b;
   RETURN_IF(make_ctx(&b.c, dims, params, prepared, workspace, workspace_bytes, stream));
   RETURN_IF(check_layer_params(dims, params));
   RETURN_IF(make_train_plan(b.c.P, &b.c.R));
   if (train_bytes < (size_t)b.c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
-  b.X = X; b.g = grads; b.tr = (float*)train;
+  b.X = X; b.dropMask = drop_mask; b.g = grads; b.tr = (float*)train;
   return backward_impl(b, d_out);
 }
 

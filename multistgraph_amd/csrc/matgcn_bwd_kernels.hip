@@ -438,6 +438,19 @@ __global__ __launch_bounds__(256) void k_colsum_all(const float* __restrict__ sr
   if (threadIdx.x == 0) out[o] = red[0];
 }
 
+// ---- dropout in front of the head (MultiATGCN.py:416, training mode): the mask comes from the caller's RNG as a
+// (B, T, N, 64) tensor of 0 / 1/(1-p);  dst[t][b][n][h] = src[t][b][n][h] * mask[b][t][n][h]  (dst may alias src)
+__global__ __launch_bounds__(256) void k_apply_mask(const float* __restrict__ src, const float* __restrict__ mask,
+                                                    float* __restrict__ dst, int B, int T, int N, int Np) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)T * B * Np * 64) return;
+  const int h = idx & 63;
+  const int n = (idx >> 6) % Np;
+  const int b = (idx / ((size_t)64 * Np)) % B;
+  const int t = idx / ((size_t)64 * Np * B);
+  dst[idx] = n < N ? src[idx] * mask[(((size_t)b * T + t) * N + n) * 64 + h] : 0.f;
+}
+
 // ---- output head backward (MultiATGCN.py:416-418): dOut (B, out, N, od) -> plain [B][Np][CH] with oc = o*od + d
 __global__ __launch_bounds__(256) void k_dout_rows(const float* __restrict__ dout, float* __restrict__ dst, int B,
                                                    int outSteps, int N, int Np, int od) {

@@ -149,6 +149,7 @@ struct TrainPlan {
   // saved per layer, each [T][B][Np][64]
   long oZ[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS], oHC[MATGCN_MAX_LAYERS];
   long oZ2[MATGCN_MAX_LAYERS], oR2[MATGCN_MAX_LAYERS], oHC2[MATGCN_MAX_LAYERS];
+  long oSeqDrop;                           // the top sequence after dropout (what the head saw), [T][B][Np][64]
   long savedFloats;                        // [0, savedFloats) is zeroed by forward_train, the rest by backward
   long oWp[MATGCN_MAX_LAYERS][2], oDWp[MATGCN_MAX_LAYERS][2], oDBias[MATGCN_MAX_LAYERS][2];
   long oDPU, oDPG, oDPU2, oDPG2;           // pre-activation gradients of every step
@@ -170,6 +171,7 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
     R->oZ[l] = take(seq); R->oR[l] = take(seq); R->oHC[l] = take(seq);
     R->oZ2[l] = take(seq); R->oR2[l] = take(seq); R->oHC2[l] = take(seq);
   }
+  R->oSeqDrop = take(seq);
   R->savedFloats = o;
   for (int l = 0; l < P.L; ++l)
     for (int part = 0; part < 2; ++part) {

@@ -101,6 +101,31 @@ class _EncoderParams(nn.Module):
                 self.res_cells.append(_DenseCellParams(cin, hidden))
 
 
+class _TrainStep(torch.autograd.Function):
+    """autograd node of one training-mode forward: matgcn_forward_train / matgcn_backward.
+    The parameters ride along as inputs so that autograd routes their gradients; X gets none (the reference
+    never differentiates w.r.t. the batch)."""
+
+    @staticmethod
+    def forward(ctx, path, x, drop_mask, names, *params):
+        out = path.forward_train(x, drop_mask)
+        ctx.path, ctx.x, ctx.mask, ctx.names = path, x, drop_mask, names
+        ctx.params = params
+        ctx.generation = path.train_generation
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        path = ctx.path
+        if path.train_generation != ctx.generation:
+            raise RuntimeError("MultiATGCN backward: another forward ran on this model between this forward and its "
+                               "backward; the saved activations live in the shared workspace (one graph at a time)")
+        state = {k: p for k, p in zip(ctx.names, ctx.params)}
+        grads = path.backward(ctx.x, d_out.contiguous(), state, ctx.mask)
+        return (None, None, None, None) + tuple(grads.get(k) if p.requires_grad else None
+                                                for k, p in zip(ctx.names, ctx.params))
+
+
 class MultiATGCN(AbstractTrafficStateModel):
     def __init__(self, config, data_feature):
         super().__init__(config, data_feature)
@@ -211,14 +236,27 @@ class MultiATGCN(AbstractTrafficStateModel):
     # ---- the plugin surface the executor calls ---------------------------------------------------
     def forward(self, batch):
         x = batch["X"]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the HIP path implements forward only (backward kernels are the next scope row, DESIGN.md): "
-                "call predict()/calculate_loss() under torch.no_grad()")
         assert x.shape[2] == self.num_nodes  # (:195)
         if x.dtype != torch.float32:
             x = x.float()
-        return self._path_for(x).forward(x.contiguous())
+        x = x.contiguous()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not needs_grad:
+            if self.training:
+                raise NotImplementedError("training-mode forward (dropout, :416) without autograd is not built: "
+                                          "call model.eval() for inference")
+            return self._path_for(x).forward(x)
+        # training step: HIP forward that keeps its activations + HIP backward behind torch autograd
+        if self.gcn_off or self.fnn_off or self.cheb_order > 2:
+            raise NotImplementedError("the HIP backward is built for cheb_order = 2 without gcn_off / fnn_off "
+                                      "(DESIGN.md section 5c); this configuration can only run under no_grad")
+        hp = self._path_for(x)
+        mask = None
+        if self.training:   # F.dropout(output, p=0.1) in front of end_conv (:416), drawn from torch's generator
+            mask = nn.functional.dropout(torch.ones(x.shape[0], self.input_window, self.num_nodes, self.hidden_dim,
+                                                    device=x.device), p=0.1, training=True)
+        named = list(self.named_parameters())
+        return _TrainStep.apply(hp, x, mask, tuple(k for k, _ in named), *[p for _, p in named])
 
     def predict(self, batch):
         return self.forward(batch)
@@ -261,7 +299,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         y_true = batch["y"]
         y_predicted = self.predict(batch)
         affine = self._affine_scaler()
-        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32:
+        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32 and not y_predicted.requires_grad:
             return masked_mae_device(y_predicted, y_true, self.start_dim, affine[0], affine[1], null_val=0.0)[0]
         y_true = self._scaler.inverse_transform(y_true[..., self.start_dim:self.end_dim])
         y_predicted = self._scaler.inverse_transform(y_predicted)

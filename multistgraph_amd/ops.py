@@ -190,12 +190,16 @@ class HotPath:
         self._static = None
         self._keep: List[torch.Tensor] = []
         self._prepared_ok = False
+        self._train = None
+        self.train_generation = 0
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _ws(self):
+        # every call that uses the workspace invalidates what an earlier forward_train left there for its backward
+        self.train_generation += 1
         return C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel() * 4)
 
     def bind(self, state: Dict[str, torch.Tensor], static_supports: Optional[torch.Tensor]):
@@ -273,32 +277,43 @@ class HotPath:
 
     # ---- training step ---------------------------------------------------
     def _train_buffer(self) -> torch.Tensor:
-        if getattr(self, "_train", None) is None:
+        if self._train is None:
             nbytes = C.c_size_t()
             _lib.check(self.lib.matgcn_train_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_train_bytes")
             self._train = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
         return self._train
 
-    def forward_train(self, x: torch.Tensor) -> torch.Tensor:
-        """matgcn_forward that keeps the activations the backward needs (in the train buffer and the workspace)."""
+    def _mask(self, drop_mask):
+        if drop_mask is None:
+            return None
+        s = self.spec
+        return _check_tensor(drop_mask, "drop_mask", (self.batch, s.in_steps, s.nodes, s.hidden))
+
+    def forward_train(self, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """matgcn_forward that keeps the activations the backward needs (in the train buffer and the workspace).
+        drop_mask: the (B, T, N, H) multipliers of the dropout in front of end_conv (training mode) or None."""
         s = self.spec
         x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        drop_mask = self._mask(drop_mask)
         self._need_prepared()
         tr = self._train_buffer()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
         ws, wsb = self._ws()
         _lib.check(self.lib.matgcn_forward_train(C.byref(self.dims), C.byref(self.params),
                                                  C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                 C.c_void_p(_ptr(drop_mask)),
                                                  C.c_void_p(out.data_ptr()), ws, wsb, C.c_void_p(tr.data_ptr()),
                                                  C.c_size_t(tr.numel() * 4), self._stream()), "matgcn_forward_train")
         return out
 
-    def backward(self, x: torch.Tensor, d_out: torch.Tensor, state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def backward(self, x: torch.Tensor, d_out: torch.Tensor, state: Dict[str, torch.Tensor],
+                 drop_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Gradients of every tensor of `state` (the dict bind() saw) that the loss depends on, keyed by the same
         names; must directly follow the matching forward_train (same workspace, same train buffer)."""
         s = self.spec
         x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
         d_out = _check_tensor(d_out, "d_out", (self.batch, s.out_window, s.nodes, s.out_dim))
+        drop_mask = self._mask(drop_mask)
         grads: Dict[str, torch.Tensor] = {}
         g = _lib.Params()
 
@@ -338,6 +353,7 @@ class HotPath:
         ws, wsb = self._ws()
         _lib.check(self.lib.matgcn_backward(C.byref(self.dims), C.byref(self.params),
                                             C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(_ptr(drop_mask)),
                                             C.c_void_p(d_out.data_ptr()), C.byref(g), ws, wsb,
                                             C.c_void_p(tr.data_ptr()), C.c_size_t(tr.numel() * 4), self._stream()),
                    "matgcn_backward")

@@ -3,11 +3,13 @@
 This is what pins the oracle: every stage the reference exposes is compared on every golden case.
 Tolerance 1e-5 max-normalised (observed: bit-exact to 1e-7).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from helpers import FULL, TINY, Case, max_norm_err
+from helpers import FULL, GOLDEN_DIR, TINY, Case, max_norm_err
 from oracle import matgcn_oracle as O
 
 TOL = 1e-5
@@ -98,3 +100,37 @@ def test_fp64_gap_is_small():
     a = O.forward(torch.from_numpy(c.x), O.to_tensors(c.state), st32, c.oracle_cfg(), False)
     b = O.forward(torch.from_numpy(c.x).double(), O.to_tensors(c.state, torch.float64), st64, c.oracle_cfg(), False)
     assert max_norm_err(a.numpy(), b.numpy()) <= 2e-5
+
+
+GRAD_CASES = sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("grad_"))
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_oracle_autograd_matches_reference_gradients(name):
+    """the gradient oracle of tests/test_backward_gpu.py (torch autograd through the restatement) against the
+    reference's own training-mode step (tests/golden/make_grad_golden.py), dropout fed from the stored mask"""
+    from oracle import matgcn_oracle as orc
+    c = Case(name)
+    gold = np.load(os.path.join(GOLDEN_DIR, "grad_%s.npz" % name))
+    shape = tuple(int(v) for v in gold["drop_shape"])
+    mask = np.unpackbits(gold["drop_bits"])[:int(np.prod(shape))].reshape(shape).astype(np.float64) / 0.9
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in c.state.items()}
+    use_static = c.adpadj == "none" or c.adjtype == "multi"
+    statics = orc.supports_as_tensors(c.gold["static_supports"], torch.float64) if use_static else []
+    cfg = c.oracle_cfg()
+    x0 = orc.fuse_heads(torch.tensor(c.x, dtype=torch.float64), p, cfg)
+    init = torch.zeros(2, c.b, c.n, 64, dtype=torch.float64)
+    seq, _ = orc.encoder(x0, init, p, statics, cfg["adjtype"], cfg["adpadj"], cfg["cheb_order"], 2, faithful=False)
+    y = orc.output_head(seq * torch.tensor(mask), p, c.out, 1)
+    assert max_norm_err(y.detach().numpy(), gold["pred"]) <= 1e-5
+    (y * torch.tensor(gold["d_out"], dtype=torch.float64)).sum().backward()
+    for k, v in p.items():
+        g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape)
+        if "grad." + k in gold:
+            got, w = g, gold["grad." + k]
+        else:
+            got, w = g.reshape(-1)[::17], gold["gsub." + k]
+        if np.abs(w).max() == 0.0:
+            assert np.abs(got).max() <= 1e-9, k
+        else:
+            assert max_norm_err(got, w) <= 2e-5, k
