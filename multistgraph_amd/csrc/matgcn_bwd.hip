@@ -92,38 +92,38 @@ int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp
   return gemm(g, P.N, b.c.s);
 }
 
-// dWp[n][s][iOfs + i][o] = sum_rows [U | mix(U)][rows][n][s][i] * dPre[rows][n][o]
-int node_weight_grad(const Bwd& b, const float* U, const float* Gall, int Cc, const float* dPre, int O, int I, int iOfs,
-                     int rows, float* dWp) {
+// where the forward left the graph-mixed rows G[s'][n][(k2, k)][i] of a range of steps: strides in floats
+struct MixedRows {
+  const float* G;
+  long sNode, sSlot, sK2, sK;
+  int K2, K;             // (k2, k) enumerate the rows of the range in the order of dPre's rows
+};
+
+// dWp[n][s][iOfs + i][o] += sum_rows [U | mix(U)][rows][n][s][i] * dPre[rows][n][o] over `rows` consecutive (t, b) rows
+// starting at row0; U rows are [Np][Cc] slabs, the mixed rows come as the forward stored them
+int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, const float* dPre, int O, int I, int iOfs,
+                     long row0, int rows, float* dWp) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
+  const float* dP = dPre + (size_t)row0 * P.Np * O;
   {  // identity slot: the rows themselves
-    GemmArgs g = gemm_args(U, dPre, dWp + (size_t)iOfs * O, Cc, O, rows);
+    GemmArgs g = gemm_args(U + (size_t)row0 * P.Np * Cc, dP, dWp + (size_t)iOfs * O, Cc, O, rows);
     g.sAm = 1; g.sAk = (long)P.Np * Cc; g.bA1 = Cc;
     g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O;
     g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O;
+    g.beta = 1.f;
     RETURN_IF(gemm(g, P.N, b.c.s));
   }
   if (P.Ks > 0) {  // dense slots: the mixed rows
-    GemmArgs g = gemm_args(Gall, dPre, dWp + (size_t)I * O + (size_t)iOfs * O, Cc, O, rows);
-    g.sAm = 1; g.sAk = (long)P.Ks * P.Np * Cc; g.bA1 = Cc; g.bA2 = (long)P.Np * Cc;
-    g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O; g.bB2 = 0;
+    GemmArgs g = gemm_args(mr.G, dP, dWp + (size_t)I * O + (size_t)iOfs * O, Cc, O, mr.K);
+    g.K2 = mr.K2;
+    g.sAm = 1; g.sAk = mr.sK; g.sAk2 = mr.sK2; g.bA1 = mr.sNode; g.bA2 = mr.sSlot;
+    g.sBk = (long)P.Np * O; g.sBk2 = (long)mr.K * P.Np * O; g.sBn = 1; g.bB1 = O; g.bB2 = 0;
     g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O; g.bC2 = (long)I * O;
-    g.nb2 = P.Ks;
+    g.nb2 = P.Ks; g.beta = 1.f;
     RETURN_IF(gemm(g, P.N, b.c.s));
   }
   return MATGCN_OK;
-}
-
-// Gall[rows][kk'][i] = sum_m S_k[n][m] U[rows][m][i]  (all dense slots, all rows)
-int mix_all(const Bwd& b, const float* U, int rows, int Cc, float* Gall) {
-  const Plan& P = b.c.P;
-  if (P.Ks <= 0) return MATGCN_OK;
-  GemmArgs g = gemm_args(b.c.prep + P.oSt, U, Gall, P.Ks * P.Np, Cc, P.N);
-  g.sAm = 1; g.sAk = P.Mp;
-  g.sBk = Cc; g.sBn = 1; g.bB1 = (long)P.Np * Cc;
-  g.sCm = Cc; g.sCn = 1; g.bC1 = (long)P.Ks * P.Np * Cc;
-  return gemm(g, rows, b.c.s);
 }
 
 // dT[n][m] += sum_{rows, i} dA[rows][slot 1][n][i] * U[rows][m][i]   (first dense slot = the adaptive adjacency)
@@ -168,7 +168,7 @@ int backward_impl(Bwd& b, const float* dOut) {
   // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
 
   // ---- scratch and outputs start from zero ----
-  RETURN_IF(zero_async(tr + R.savedFloats, R.floats - R.savedFloats, s));
+  RETURN_IF(zero_async(tr + R.keepFloats, R.floats - R.keepFloats, s));
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
   RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
@@ -196,7 +196,9 @@ int backward_impl(Bwd& b, const float* dOut) {
   hipLaunchKernelGGL(k_dout_rows, dim3(blocks_for((size_t)B * Np * P.CH)), dim3(256), 0, s, dOut, dOutRows, B,
                      P.CH / P.od, N, Np, P.od);
   CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum_all, dim3((unsigned)P.CH), dim3(256), 0, s, dOutRows, (size_t)B, N, Np, P.CH,
+  auto pad_pow2 = [](int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; };
+  RETURN_IF(zero_async(g->end_conv_bias, P.CH, s));
+  hipLaunchKernelGGL(k_colsum_all, dim3(256), dim3(256), 0, s, dOutRows, (size_t)B, N, Np, P.CH, pad_pow2(P.CH),
                      g->end_conv_bias);
   CHECK_LAUNCH();
   const float* seqTop = b.dropMask ? tr + R.oSeqDrop : c.ws + P.oSeq[P.L - 1];   // what the head convolved
@@ -251,7 +253,7 @@ int backward_impl(Bwd& b, const float* dOut) {
       a.dh = DH; a.dr = tr + R.oDR;
       a.B = B; a.N = N; a.Np = Np; a.S = S;
       const dim3 eg(blocks_for((size_t)slab));
-      hipLaunchKernelGGL(k_chain_res_out, eg, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
       CHECK_LAUNCH();
       {  // gradient of z2*ha = dpre_u2 . RU[:, C:]
         GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
@@ -315,25 +317,40 @@ int backward_impl(Bwd& b, const float* dOut) {
       q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
       RETURN_IF(gemm(q2, 1, s));
     }
-    // node-adaptive weight gradients (plain folded layout) and biases
-    float* Gall = tr + R.oGall;
+    // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
     float* dWpG = tr + R.oDWp[l][0];
     float* dWpU = tr + R.oDWp[l][1];
-    RETURN_IF(mix_all(b, Xall, rowsTB, C, Gall));
-    RETURN_IF(node_weight_grad(b, Xall, Gall, C, DPG, 128, I, 0, rowsTB, dWpG));
-    RETURN_IF(node_weight_grad(b, Xall, Gall, C, DPU, 64, I, 0, rowsTB, dWpU));
-    if (adp) RETURN_IF(adaptive_grad(b, DAx, Xall, rowsTB, C, dT));
-    RETURN_IF(mix_all(b, Hprev, rowsTB, H, Gall));
-    RETURN_IF(node_weight_grad(b, Hprev, Gall, H, DPG, 128, I, C, rowsTB, dWpG));
-    if (adp) RETURN_IF(adaptive_grad(b, DAg, Hprev, rowsTB, H, dT));
-    RETURN_IF(mix_all(b, ZH, rowsTB, H, Gall));
-    RETURN_IF(node_weight_grad(b, ZH, Gall, H, DPU, 64, I, C, rowsTB, dWpU));
-    if (adp) RETURN_IF(adaptive_grad(b, DAu, ZH, rowsTB, H, dT));
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128)), dim3(256), 0, s, DPG, (size_t)rowsTB, N, Np,
-                       128, tr + R.oDBias[l][0]);
+    const long gStep = (long)N * B * P.Ks * H;
+    {  // recurrent rows: [T][N][B][Ks][64]
+      MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
+      RETURN_IF(node_weight_grad(b, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
+      MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
+      RETURN_IF(node_weight_grad(b, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
+    }
+    if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
+      const long ld = rup((long)rowsTB * P.C0, 64);
+      MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
+      RETURN_IF(node_weight_grad(b, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
+      RETURN_IF(node_weight_grad(b, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
+    } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
+      for (int t0 = 0; t0 < T;) {
+        const int nt = chunk_steps(P, t0);
+        MixedRows mx = {tr + R.oGX[l] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, nt * B};
+        RETURN_IF(node_weight_grad(b, Xall, mx, C, DPG, 128, I, 0, (long)t0 * B, nt * B, dWpG));
+        RETURN_IF(node_weight_grad(b, Xall, mx, C, DPU, 64, I, 0, (long)t0 * B, nt * B, dWpU));
+        t0 += nt;
+      }
+    }
+    if (adp) {
+      RETURN_IF(adaptive_grad(b, DAx, Xall, rowsTB, C, dT));
+      RETURN_IF(adaptive_grad(b, DAg, Hprev, rowsTB, H, dT));
+      RETURN_IF(adaptive_grad(b, DAu, ZH, rowsTB, H, dT));
+    }
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, s, DPG, (size_t)rowsTB, N,
+                       Np, 128, tr + R.oDBias[l][0]);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64)), dim3(256), 0, s, DPU, (size_t)rowsTB, N, Np, 64,
-                       tr + R.oDBias[l][1]);
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, s, DPU, (size_t)rowsTB, N, Np,
+                       64, tr + R.oDBias[l][1]);
     CHECK_LAUNCH();
     // residual nn.Linear gradients (MultiATGCN.py:139-150)
     {
@@ -347,9 +364,11 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(linear_weight_grad(b, DPG2, 128, HA, H, rows, I, C, gg.weight));
       RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
       RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
-      hipLaunchKernelGGL(k_colsum_all, dim3(128), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, gg.bias);
+      RETURN_IF(zero_async(gg.bias, 128, s));
+      RETURN_IF(zero_async(gu.bias, 64, s));
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
       CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_colsum_all, dim3(64), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, gu.bias);
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
       CHECK_LAUNCH();
     }
     if (l > 0) cur ^= 1;

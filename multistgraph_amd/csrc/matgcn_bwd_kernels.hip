@@ -290,16 +290,15 @@ __device__ __forceinline__ float ha_of(const ChainArgs& a, size_t idx) {
 
 __global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
   __shared__ float red[256];
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t total = (size_t)a.B * a.Np * 64;
+  const float g = sigmoid_f(a.blend[0]);
   float part = 0.f;
-  if (idx < total) {
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int n = (idx >> 6) % a.Np;
     const float dhp = a.dseq[idx] + (a.dcarry ? a.dcarry[idx] : 0.f);
-    const float g = sigmoid_f(a.blend[0]);
     const float ha = ha_of(a, idx), r2 = a.r2[idx], hc2 = a.hc2[idx];
     const float res = r2 * ha + (1.f - r2) * hc2;
-    if (n < a.N) part = dhp * (ha - res);
+    if (n < a.N) part += dhp * (ha - res);
     const float dres = (1.f - g) * dhp;
     a.dha[idx] = g * dhp + dres * r2;
     a.dpu2[idx] = dres * (1.f - r2) * (1.f - hc2 * hc2);
@@ -311,10 +310,7 @@ __global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float g = sigmoid_f(a.blend[0]);
-    unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
-  }
+  if (threadIdx.x == 0) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
 }
 
 // part 2: gradient of z2*ha arrived -> dz2, dha += dzh2 * z2, gate pre-activation gradient of the residual cell
@@ -407,35 +403,40 @@ __global__ __launch_bounds__(256) void k_x0_time_major(const float* __restrict__
   dst[idx] = src[((size_t)b * T + t) * per + q];
 }
 
-// column sums over the rows of a [rows][Np][O] tensor, per node: out[n][o] = sum_rows src[row][n][o]
+// column sums over the rows of a [rows][Np][O] tensor, per node: out[n][o] += sum_rows src[row][n][o]; the rows are
+// split over gridDim.y workgroups that meet in `out` with atomics (out holds its initial value beforehand)
 __global__ __launch_bounds__(256) void k_node_colsum(const float* __restrict__ src, size_t rows, int N, int Np, int O,
                                                      float* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= N * O) return;
   const int n = idx / O, o = idx - n * O;
+  const size_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const size_t r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
   float s = 0.f;
-  for (size_t r = 0; r < rows; ++r) s += src[(r * Np + n) * O + o];
-  out[idx] = s;
+  for (size_t r = r0; r < r1; ++r) s += src[(r * Np + n) * O + o];
+  unsafeAtomicAdd(&out[idx], s);
 }
 
-// column sums over rows AND nodes: out[o] = sum_{row, n < N} src[row][n][o]   (nn.Linear bias gradients)
+// column sums over rows AND nodes: out[o] += sum_{row, n < N} src[row][n][o]   (nn.Linear / Conv2d bias gradients).
+// A workgroup walks items (row, n) with 256/Opad of them in flight, lanes along o (coalesced); partial sums meet in
+// LDS and then in `out` with one atomic per column and workgroup (out holds its initial value beforehand).
 __global__ __launch_bounds__(256) void k_colsum_all(const float* __restrict__ src, size_t rows, int N, int Np, int O,
-                                                    float* __restrict__ out) {
+                                                    int Opad, float* __restrict__ out) {
   __shared__ float red[256];
-  const int o = blockIdx.x;
-  float s = 0.f;
+  const int o = threadIdx.x % Opad, item = threadIdx.x / Opad, per = 256 / Opad;
   const size_t total = rows * N;
-  for (size_t q = threadIdx.x; q < total; q += 256) {
-    const size_t r = q / N, n = q - r * N;
-    s += src[(r * Np + n) * O + o];
-  }
+  float s = 0.f;
+  if (o < O)
+    for (size_t q = (size_t)blockIdx.x * per + item; q < total; q += (size_t)gridDim.x * per) {
+      const size_t r = q / N, n = q - r * N;
+      s += src[(r * Np + n) * O + o];
+    }
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-    __syncthreads();
+  if (item == 0 && o < O) {
+    for (int q = 1; q < per; ++q) s += red[q * Opad + o];
+    unsafeAtomicAdd(&out[o], s);
   }
-  if (threadIdx.x == 0) out[o] = red[0];
 }
 
 // ---- dropout in front of the head (MultiATGCN.py:416, training mode): the mask comes from the caller's RNG as a

@@ -150,13 +150,17 @@ struct TrainPlan {
   long oZ[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS], oHC[MATGCN_MAX_LAYERS];
   long oZ2[MATGCN_MAX_LAYERS], oR2[MATGCN_MAX_LAYERS], oHC2[MATGCN_MAX_LAYERS];
   long oSeqDrop;                           // the top sequence after dropout (what the head saw), [T][B][Np][64]
-  long savedFloats;                        // [0, savedFloats) is zeroed by forward_train, the rest by backward
+  long savedFloats;                        // [0, savedFloats) is zeroed by forward_train
+  // graph-mixed rows of every step as the forward wrote them, [T][N][B][Ks][64] (x part: per chunk [N][nt*B][Ks][64]);
+  // written in full by forward_train, never zeroed
+  long oGH[MATGCN_MAX_LAYERS], oGZH[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS];
+  long keepFloats;                         // [keepFloats, floats) is zeroed by backward
   long oWp[MATGCN_MAX_LAYERS][2], oDWp[MATGCN_MAX_LAYERS][2], oDBias[MATGCN_MAX_LAYERS][2];
   long oDPU, oDPG, oDPU2, oDPG2;           // pre-activation gradients of every step
   long oDSeq[2];                           // gradient of a layer's output sequence (ping-pong)
   long oDAg, oDAu;                         // [T][B][S][Np][64] gradient of [s | mix(s)] of both AGCNs, h columns
   long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
-  long oX0tm, oHprev, oZH, oHA, oZ2HA, oGall, oDAx, oDX0;
+  long oX0tm, oHprev, oZH, oHA, oZ2HA, oDAx, oDX0;
   long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
   long floats;
 };
@@ -173,6 +177,12 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   }
   R->oSeqDrop = take(seq);
   R->savedFloats = o;
+  const long gAll = (long)P.T * P.N * P.B * P.Ks * H;
+  for (int l = 0; l < P.L; ++l) {
+    R->oGH[l] = take(gAll); R->oGZH[l] = take(gAll);
+    if (l > 0) R->oGX[l] = take(gAll);
+  }
+  R->keepFloats = o;
   for (int l = 0; l < P.L; ++l)
     for (int part = 0; part < 2; ++part) {
       const long O = part == 0 ? 128 : 64, I = P.Cl[l] + H;
@@ -186,7 +196,6 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab); R->oMixOut = take(slab);
   R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
   R->oHprev = take(seq); R->oZH = take(seq); R->oHA = take(seq); R->oZ2HA = take(seq);
-  R->oGall = take(seq * (P.Ks > 0 ? P.Ks : 1));
   R->oDAx = take(seq * R->S);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
   R->oDT = take((long)P.N * P.N); R->oDL = take((long)P.N * P.N);
@@ -350,12 +359,21 @@ int fold_x0(const Ctx& c, const float* xin, int Tq, hipStream_t s) {
   return launch_ok();
 }
 
+// x-part chunks of layers >= 1: the first are short (1, 1, 2 steps) so that a layer starts one step behind the one below
+inline int chunk_steps(const Plan& P, int t) {
+  int nt = (t < 2) ? 1 : (t < 4 ? 2 : P.Tc);
+  if (nt > P.Tc) nt = P.Tc;
+  if (t + nt > P.T) nt = P.T - t;
+  return nt;
+}
+
 // layers >= 1: hoisted x part of steps [t0, t0+nt) -> PX_l[t0..].  xin: time-major rows [nt*B][Np][64] of the
 // layer below (MultiATGCN.py:106-108 restricted to the x rows, + bias)
 int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s) {
   const Plan& P = c.P;
   const int rows = P.B * nt;
-  float* GX = c.ws + P.oGX[l];
+  // training keeps the mixed rows of every chunk for the weight gradients
+  float* GX = c.train ? c.train + c.R.oGX[l] + (size_t)t0 * P.N * P.B * P.Ks * H : c.ws + P.oGX[l];
   RETURN_IF(mix_rows(P, c.prep + P.oSt, xin, rows, GX, s));
   Px16Args a;
   a.x = xin; a.g = GX; a.w = c.prep + P.oWx[l]; a.bias = c.prep + P.oBx[l];
@@ -383,6 +401,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   float* Hx = c.ws + P.oHx[l];
   float* ZHx = c.ws + P.oZHx[l];
   float* G = c.ws + P.oG[l];
+  if (c.train && res)   // training keeps the mixed rows of every step (weight gradients of the backward)
+    G = c.train + (phase < 2 ? c.R.oGH[l] : c.R.oGZH[l]) + (size_t)t * P.N * P.B * P.Ks * H;
   float* R = c.ws + P.oR[l];
   if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true);
   if (phase == 2) return mix_rows(P, St, ZHx, P.B, G, s, true);
@@ -500,9 +520,7 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
       if (l > 0 && t == nextChunk) {
         // x-part chunk [t, t+nt) of this layer, as soon as the layer below has produced those steps; the first
         // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
-        int nt = (t < 2) ? 1 : (t < 4 ? 2 : P.Tc);
-        if (nt > P.Tc) nt = P.Tc;
-        if (t + nt > P.T) nt = P.T - t;
+        const int nt = chunk_steps(P, t);
         nextChunk = t + nt;
         if (multi) HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
         RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs));
