@@ -25,11 +25,29 @@ GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K
   return g;
 }
 
-int gemm(const GemmArgs& g, int nb1, hipStream_t s) {
+template <int ROLE>
+void launch_bgemm(const dim3& grid, hipStream_t s, const GemmArgs& g) {
+  hipLaunchKernelGGL(k_bgemm<ROLE>, grid, dim3(256), 0, s, g);
+}
+
+int gemm(const GemmArgs& g, int nb1, hipStream_t s, int role = BG_GENERIC) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K2 <= 0 || nb1 <= 0) return MATGCN_OK;
   const long gx = (g.N + 63) / 64, gy = (g.M + 63) / 64, gz = (long)nb1 * g.nb2 * g.split;
   if (gy > 65535 || gz > 65535) return MATGCN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_bgemm, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), 0, s, g);
+  const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
+  switch (role) {
+    case BG_CHAIN_DENSE: launch_bgemm<BG_CHAIN_DENSE>(grid, s, g); break;
+    case BG_CHAIN_NODE: launch_bgemm<BG_CHAIN_NODE>(grid, s, g); break;
+    case BG_CHAIN_MIX: launch_bgemm<BG_CHAIN_MIX>(grid, s, g); break;
+    case BG_X_NODE: launch_bgemm<BG_X_NODE>(grid, s, g); break;
+    case BG_X_MIX: launch_bgemm<BG_X_MIX>(grid, s, g); break;
+    case BG_WGRAD: launch_bgemm<BG_WGRAD>(grid, s, g); break;
+    case BG_ADJ: launch_bgemm<BG_ADJ>(grid, s, g); break;
+    case BG_LINEAR: launch_bgemm<BG_LINEAR>(grid, s, g); break;
+    case BG_POOL: launch_bgemm<BG_POOL>(grid, s, g); break;
+    case BG_HEAD: launch_bgemm<BG_HEAD>(grid, s, g); break;
+    default: launch_bgemm<BG_GENERIC>(grid, s, g); break;
+  }
   return launch_ok();
 }
 
@@ -66,17 +84,30 @@ StackMap build_stack_map(const Plan& P, const matgcn_dims* D, const matgcn_param
   return map;
 }
 
-// dst[rows][m][i] (+)= sum_kk' St[m][kk'] * src[rows][slot 1..][kk'][i]: the transposed graph mix of the dense
-// slots of a [rows][S][Np][Cc] gradient, one GEMM batched over the rows
+// dst[rows][m][i] = sum_kk StP[kk][m] * src[rows][slot 1..][kk][i]: the transposed graph mix of the dense slots of a
+// [rows][S][Np][Cc] gradient.  With 64 feature columns this is the forward's graph-mix kernel run on the plain stack
+// (reduction over (k, n), one column tile per row); narrower inputs (layer 0) take the generic GEMM.
 int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst) {
   const Plan& P = b.c.P;
   if (P.Ks <= 0) return MATGCN_OK;
   const int S = b.c.R.S;
+  if (Cc == H) {
+    MixArgs a;
+    a.St = b.tr + b.c.R.oStP; a.ldS = P.NpC;
+    a.X = src + (size_t)P.Np * H; a.xTileStride = (long)S * P.Np * H; a.ldX = H;
+    a.out = dst; a.sN = H; a.sK = 0; a.sT = (long)P.Np * H;
+    const long outFloats = (long)rows * P.Np * H;
+    a.outFloats = outFloats < (1L << 29) ? outFloats : 0;
+    a.Np = P.NpC; a.N = P.N; a.Ks = 1; a.nK = P.Ks * P.Np / 16; a.nColTiles = rows;
+    a.nRowTiles = P.NpC / 64;
+    hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * rows)), dim3(256), 0, b.c.s, a);
+    return launch_ok();
+  }
   GemmArgs g = gemm_args(b.c.prep + P.oSt, src + (size_t)P.Np * Cc, dst, P.N, Cc, P.Ks * P.Np);
   g.sAm = P.Mp; g.sAk = 1;
   g.sBk = Cc; g.sBn = 1; g.bB1 = (long)S * P.Np * Cc;
   g.sCm = Cc; g.sCn = 1; g.bC1 = (long)P.Np * Cc;
-  return gemm(g, rows, b.c.s);
+  return gemm(g, rows, b.c.s, rows > P.B ? BG_X_MIX : BG_CHAIN_MIX);
 }
 
 // dA[rows][s][n][i] (+)= dPre[rows][n][0:O] . Wp[n][s][iOfs + i][0:O]^T for every node and slot
@@ -89,7 +120,7 @@ int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp
   g.sBk = 1; g.sBn = O; g.bB1 = (long)S * I * O; g.bB2 = (long)I * O;
   g.sCm = (long)S * P.Np * Cc; g.sCn = 1; g.bC1 = Cc; g.bC2 = (long)P.Np * Cc;
   g.nb2 = S; g.beta = beta;
-  return gemm(g, P.N, b.c.s);
+  return gemm(g, P.N, b.c.s, rows > P.B ? BG_X_NODE : BG_CHAIN_NODE);
 }
 
 // where the forward left the graph-mixed rows G[s'][n][(k2, k)][i] of a range of steps: strides in floats
@@ -112,7 +143,7 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
     g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O;
     g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O;
     g.beta = 1.f;
-    RETURN_IF(gemm(g, P.N, b.c.s));
+    RETURN_IF(gemm(g, P.N, b.c.s, BG_WGRAD));
   }
   if (P.Ks > 0) {  // dense slots: the mixed rows
     GemmArgs g = gemm_args(mr.G, dP, dWp + (size_t)I * O + (size_t)iOfs * O, Cc, O, mr.K);
@@ -121,7 +152,7 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
     g.sBk = (long)P.Np * O; g.sBk2 = (long)mr.K * P.Np * O; g.sBn = 1; g.bB1 = O; g.bB2 = 0;
     g.sCm = O; g.sCn = 1; g.bC1 = (long)S * I * O; g.bC2 = (long)I * O;
     g.nb2 = P.Ks; g.beta = 1.f;
-    RETURN_IF(gemm(g, P.N, b.c.s));
+    RETURN_IF(gemm(g, P.N, b.c.s, BG_WGRAD));
   }
   return MATGCN_OK;
 }
@@ -136,7 +167,7 @@ int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int C
   g.sBk = 1; g.sBn = Cc; g.sBk2 = (long)P.Np * Cc;
   g.sCm = P.N; g.sCn = 1;
   g.mode = 1; g.split = 48;
-  return gemm(g, 1, b.c.s);
+  return gemm(g, 1, b.c.s, BG_ADJ);
 }
 
 // nn.Linear weight gradient: dW[o][iOfs + i] = sum_rows dPre[rows][o] * In[rows][i]   (rows = every (t, b, n))
@@ -147,7 +178,7 @@ int linear_weight_grad(const Bwd& b, const float* dPre, int O, const float* In, 
   g.sBk = Cc; g.sBn = 1;
   g.sCm = I; g.sCn = 1;
   g.mode = 1; g.split = 256;
-  return gemm(g, 1, b.c.s);
+  return gemm(g, 1, b.c.s, BG_LINEAR);
 }
 
 int backward_impl(Bwd& b, const float* dOut) {
@@ -178,6 +209,11 @@ int backward_impl(Bwd& b, const float* dOut) {
   int slotOf[MATGCN_MAX_STACK];
   slot_map(P, map, slotOf);
 
+  if (P.Ks > 0) {  // plain copy of the support stack for the transposed mixes
+    hipLaunchKernelGGL(k_stack_plain, dim3((unsigned)((P.Ks * Np + 31) / 32), (unsigned)((P.NpC + 31) / 32)), dim3(256),
+                       0, s, c.prep + P.oSt, P.Mp, N, P.Ks * Np, P.NpC, tr + R.oStP);
+    CHECK_LAUNCH();
+  }
   // plain folded weights of both AGCNs of every layer
   for (int l = 0; l < P.L; ++l)
     for (int part = 0; part < 2; ++part) {
@@ -209,7 +245,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     q.sBk = (long)T * H; q.sBn = 1; q.bB1 = H;
     q.sCm = H; q.sCn = 1; q.bC1 = slab; q.bC2 = (long)Np * H;
     q.nb2 = B;
-    RETURN_IF(gemm(q, T, s));
+    RETURN_IF(gemm(q, T, s, BG_HEAD));
     RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * T * H, s));
     GemmArgs w = gemm_args(dOutRows, seqTop, g->end_conv_weight, P.CH, H, N);
     w.K2 = B;
@@ -217,7 +253,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     w.sBk = H; w.sBn = 1; w.sBk2 = (long)Np * H; w.bB1 = slab;
     w.sCm = (long)T * H; w.sCn = 1; w.bC1 = H;
     w.mode = 1; w.split = 16;
-    RETURN_IF(gemm(w, T, s));
+    RETURN_IF(gemm(w, T, s, BG_HEAD));
     if (b.dropMask) {
       hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)T * slab)), dim3(256), 0, s, dSeq, b.dropMask, dSeq, B, T,
                          N, Np);
@@ -258,14 +294,14 @@ int backward_impl(Bwd& b, const float* dOut) {
       {  // gradient of z2*ha = dpre_u2 . RU[:, C:]
         GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
         q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s));
+        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
       }
       hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
       CHECK_LAUNCH();
       {  // dha += dpre_g2 . RG[:, C:]
         GemmArgs q = gemm_args(DPG2 + 2 * at, RG + C, DHa, B * Np, H, 128);
         q.sAm = 128; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1; q.beta = 1.f;
-        RETURN_IF(gemm(q, 1, s));
+        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
       }
       hipLaunchKernelGGL(k_chain_cell_out, eg, dim3(256), 0, s, a);
       CHECK_LAUNCH();
@@ -416,11 +452,11 @@ int backward_impl(Bwd& b, const float* dOut) {
         const float* src = dWp + (size_t)slotOf[k] * IO;
         GemmArgs q = gemm_args(EK + (size_t)k * N * P.d, src, ag.weights_pool + (size_t)k * IO, P.d, (int)IO, N);
         q.sAm = 1; q.sAk = P.d; q.sBk = (long)S * IO; q.sBn = 1; q.sCm = (long)Kt * IO; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s));
+        RETURN_IF(gemm(q, 1, s, BG_POOL));
         GemmArgs e = gemm_args(src, ap.weights_pool + (size_t)k * IO, TmpK + (size_t)k * N * P.d, N, P.d, (int)IO);
         e.sAm = (long)S * IO; e.sAk = 1; e.sBk = 1; e.sBn = (long)Kt * IO; e.sCm = P.d; e.sCn = 1;
         e.mode = 1; e.split = 32;
-        RETURN_IF(gemm(e, 1, s));
+        RETURN_IF(gemm(e, 1, s, BG_POOL));
       }
       hipLaunchKernelGGL(k_emb_grad, dim3(blocks_for((size_t)N * P.d), (unsigned)Kt), dim3(256), 0, s, TmpK, FK,
                          prm->node_emb, wg, Kt, N, P.d, g->node_emb, dgain);
@@ -538,7 +574,7 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
   g.mode = (int)desc[20]; g.split = (int)desc[21];
   g.alpha = alpha; g.beta = beta;
   if (g.nb2 < 1 || g.split < 1 || nb1 < 1 || g.mode < 0 || g.mode > 1) return MATGCN_ERR_BAD_ARG;
-  return gemm(g, nb1, (hipStream_t)stream);
+  return gemm(g, nb1, (hipStream_t)stream, BG_GENERIC);
 }
 
 }  // extern "C"

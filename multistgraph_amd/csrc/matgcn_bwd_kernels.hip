@@ -31,6 +31,10 @@ struct GemmArgs {
 
 #define BG_LD 80   // LDS row pitch (floats): lanes with kq = 0..3 land 16 banks apart
 
+// ROLE only names the instantiation, so that profilers list the call sites of the backward on separate lines
+enum { BG_GENERIC = 0, BG_CHAIN_DENSE, BG_CHAIN_NODE, BG_CHAIN_MIX, BG_X_NODE, BG_X_MIX, BG_WGRAD, BG_ADJ, BG_LINEAR,
+       BG_POOL, BG_HEAD, BG_ROLES };
+template <int ROLE>
 __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   __shared__ float As[2][16][BG_LD];
   __shared__ float Bs[2][16][BG_LD];
@@ -360,6 +364,24 @@ __global__ __launch_bounds__(256) void k_chain_carry(ChainArgs a) {
   float v = a.dh[idx] + a.dhA[((b * a.S) * a.Np + n) * 64 + o];
   if (a.dhMix) v += a.dhMix[idx];
   a.dh[idx] = v;
+}
+
+// plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
+// kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
+__global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
+                                                     float* __restrict__ StP) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: kk block, by: m block
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int m = by + j, kk = bx + tx;
+    tile[j][tx] = (m < N && kk < rowsKK) ? St[(size_t)m * ldS + kk] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int kk = bx + j, m = by + tx;
+    if (kk < rowsKK && m < ldP) StP[(size_t)kk * ldP + m] = tile[tx][j];
+  }
 }
 
 // ---- small helpers -------------------------------------------------------------------------------------------

@@ -162,6 +162,7 @@ struct TrainPlan {
   long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
   long oX0tm, oHprev, oZH, oHA, oZ2HA, oDAx, oDX0;
   long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
+  long oStP;                               // [Ks*Np][NpC] plain support stack (A operand of the transposed mix)
   long floats;
 };
 
@@ -202,6 +203,7 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
   R->oTmpK = take((long)P.KtotOrig * P.N * P.d); R->oDGain = take(64);
   R->oDOutRows = take((long)P.B * P.Np * P.CH);
+  R->oStP = take((long)P.Ks * P.Np * P.NpC);
   R->floats = o;
   return MATGCN_OK;
 }
