@@ -127,6 +127,37 @@ def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     return out
 
 
+def train_step_times(model, batch, w, warm=2, steps=5):
+    """One optimisation step as TrafficStateExecutor._train_epoch runs it (traffic_state_executor.py:411-422):
+    loss = model.calculate_loss(batch); loss.backward(); optimizer.step() - forward_train + backward on the HIP
+    path, Adam in torch.  Reported beside the headline; runs last because it moves the weights."""
+    model.train()
+    model.cache_prepared = True
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    fwd, bwd, adam, losses = [], [], [], []
+    for i in range(warm + steps):
+        opt.zero_grad()
+        ev[0].record()
+        loss = model.calculate_loss(batch)
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        opt.step()
+        ev[3].record()
+        torch.cuda.synchronize()
+        losses.append(float(loss.detach()))
+        if i >= warm:
+            fwd.append(ev[0].elapsed_time(ev[1])); bwd.append(ev[1].elapsed_time(ev[2])); adam.append(ev[2].elapsed_time(ev[3]))
+    model.eval()
+    total = statistics.mean(fwd) + statistics.mean(bwd) + statistics.mean(adam)
+    return {"forward_ms": statistics.mean(fwd), "backward_ms": statistics.mean(bwd), "optimizer_ms": statistics.mean(adam),
+            "ms_per_step": total, "node_steps_per_s": w["batch"] * 24 * w["nodes"] / (total * 1e-3), "steps": steps,
+            "loss_first": losses[0], "loss_last": losses[-1],
+            "note": "training step through the plugin surface: HIP forward that keeps activations (incl. the prepare "
+                    "after every weight update) + HIP backward behind torch autograd + torch Adam; dropout p=0.1 on"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +166,7 @@ def main():
     ap.add_argument("--workload", default="bm403", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing (N=1 only)")
     ap.add_argument("--cache-prepared", action="store_true",
                     help="keep matgcn_prepare out of the timed steps (inference with frozen weights)")
     ap.add_argument("--serial-streams", action="store_true",
@@ -285,6 +317,8 @@ def main():
             result["mae_at_12_cpu"] = float(masked_mae(pred_cpu[:, min(12, w["out"]) - 1],
                                                        torch.from_numpy(y_np)[:, min(12, w["out"]) - 1, :, 0:1]).item())
             result["gpu_over_cpu"] = value / base["value"]
+        if world == 1 and not args.no_train_step:
+            result["train_step"] = train_step_times(model, batch, w)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
