@@ -206,7 +206,8 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
  * F.dropout p = 0.1) as a (B, T, N, H) device tensor of multipliers 0 or 1/(1-p) drawn by the caller's RNG
  * (torch: F.dropout(torch.ones(B,T,N,H))); the same mask goes to the matching matgcn_backward.
  * Reductions that meet in one address use fp32 atomics: gradients are reproducible to rounding, not bitwise.
- * Not built yet for training (MATGCN_ERR_UNSUPPORTED): cheb_order > 2, gcn_off, fnn_off. */
+ * With gcn_off the dense cells' nn.Linear gradients come back in res_gate / res_update (as their weights go in);
+ * with fnn_off drop_mask is (B, 1, N, H). */
 typedef struct matgcn_agcn_grads {
   float* weights_g;
   float* weights_pool;

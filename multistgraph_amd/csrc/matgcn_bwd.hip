@@ -13,7 +13,8 @@
 // and at the end the parameter-only part: node-adaptive weights -> pools / node_emb / weights_g, adaptive adjacency
 // -> node_vec1/2 (or node_emb), head fusion -> weight_ts / weight_tsg.
 //
-// Not yet built for training (MATGCN_ERR_UNSUPPORTED): cheb_order > 2, gcn_off, fnn_off.
+// Every configuration of the forward trains: any cheb_order (the recursion is back-propagated into the adaptive
+// adjacency), gcn_off (dense GRU layers), fnn_off (head over the last step), node_specific_off (node_emb frozen).
 
 namespace {
 
@@ -157,17 +158,21 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
   return MATGCN_OK;
 }
 
-// dT[n][m] += sum_{rows, i} dA[rows][slot 1][n][i] * U[rows][m][i]   (first dense slot = the adaptive adjacency)
+// dT_j[n][m] += sum_{rows, i} dA[rows][slot 1 + j][n][i] * U[rows][m][i] for the `per` Chebyshev orders of the adaptive
+// adjacency (first-order support 0 is never diagonal: its orders are the dense slots 0 .. per-1)
 int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int Cc, float* dT) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
-  GemmArgs g = gemm_args(dA + (size_t)P.Np * Cc, U, dT, P.N, P.N, Cc);
-  g.K2 = rows;
-  g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;
-  g.sBk = 1; g.sBn = Cc; g.sBk2 = (long)P.Np * Cc;
-  g.sCm = P.N; g.sCn = 1;
-  g.mode = 1; g.split = 48;
-  return gemm(g, 1, b.c.s, BG_ADJ);
+  for (int j = 0; j < P.per; ++j) {
+    GemmArgs g = gemm_args(dA + (size_t)(1 + j) * P.Np * Cc, U, dT + (size_t)j * P.N * P.N, P.N, P.N, Cc);
+    g.K2 = rows;
+    g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;
+    g.sBk = 1; g.sBn = Cc; g.sBk2 = (long)P.Np * Cc;
+    g.sCm = P.N; g.sCn = 1;
+    g.mode = 1; g.split = 48;
+    RETURN_IF(gemm(g, 1, b.c.s, BG_ADJ));
+  }
+  return MATGCN_OK;
 }
 
 // nn.Linear weight gradient: dW[o][iOfs + i] = sum_rows dPre[rows][o] * In[rows][i]   (rows = every (t, b, n))
@@ -193,9 +198,9 @@ int backward_impl(Bwd& b, const float* dOut) {
   const int S = R.S, T = P.T, B = P.B, Np = P.Np, N = P.N;
   const long slab = (long)B * Np * H;
   const int rowsTB = T * B;
-  if (D->cheb_k > 2 || P.gcnOff || P.headT != T) return MATGCN_ERR_UNSUPPORTED;
   if ((long)rowsTB * Np >= (1L << 31)) return MATGCN_ERR_UNSUPPORTED;
-  const bool adp = D->adp_mode != MATGCN_ADP_NONE;
+  const bool adp = D->adp_mode != MATGCN_ADP_NONE && !P.gcnOff;
+  const int hT = P.headT, tOff = T - P.headT;     // fnn_off: the head sees the last step only (MultiATGCN.py:412)
   // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
 
   // ---- scratch and outputs start from zero ----
@@ -203,7 +208,8 @@ int backward_impl(Bwd& b, const float* dOut) {
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
   RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
-  if (!g->weights_gru || !g->weight_tsg || !g->end_conv_weight || !g->end_conv_bias) return MATGCN_ERR_NULL;
+  if ((!P.gcnOff && !g->weights_gru) || !g->weight_tsg || !g->end_conv_weight || !g->end_conv_bias)
+    return MATGCN_ERR_NULL;
 
   const StackMap map = build_stack_map(P, D, prm);
   int slotOf[MATGCN_MAX_STACK];
@@ -215,7 +221,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     CHECK_LAUNCH();
   }
   // plain folded weights of both AGCNs of every layer
-  for (int l = 0; l < P.L; ++l)
+  for (int l = 0; l < P.L && !P.gcnOff; ++l)
     for (int part = 0; part < 2; ++part) {
       const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
       PlainPrep q;
@@ -240,23 +246,23 @@ int backward_impl(Bwd& b, const float* dOut) {
   const float* seqTop = b.dropMask ? tr + R.oSeqDrop : c.ws + P.oSeq[P.L - 1];   // what the head convolved
   float* dSeq = tr + R.oDSeq[0];
   {
-    GemmArgs q = gemm_args(dOutRows, prm->end_conv_weight, dSeq, N, H, P.CH);
+    GemmArgs q = gemm_args(dOutRows, prm->end_conv_weight, dSeq + (size_t)tOff * slab, N, H, P.CH);
     q.sAm = P.CH; q.sAk = 1; q.bA2 = (long)Np * P.CH;
-    q.sBk = (long)T * H; q.sBn = 1; q.bB1 = H;
+    q.sBk = (long)hT * H; q.sBn = 1; q.bB1 = H;
     q.sCm = H; q.sCn = 1; q.bC1 = slab; q.bC2 = (long)Np * H;
     q.nb2 = B;
-    RETURN_IF(gemm(q, T, s, BG_HEAD));
-    RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * T * H, s));
-    GemmArgs w = gemm_args(dOutRows, seqTop, g->end_conv_weight, P.CH, H, N);
+    RETURN_IF(gemm(q, hT, s, BG_HEAD));
+    RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * hT * H, s));
+    GemmArgs w = gemm_args(dOutRows, seqTop + (size_t)tOff * slab, g->end_conv_weight, P.CH, H, N);
     w.K2 = B;
     w.sAm = 1; w.sAk = P.CH; w.sAk2 = (long)Np * P.CH;
     w.sBk = H; w.sBn = 1; w.sBk2 = (long)Np * H; w.bB1 = slab;
-    w.sCm = (long)T * H; w.sCn = 1; w.bC1 = H;
+    w.sCm = (long)hT * H; w.sCn = 1; w.bC1 = H;
     w.mode = 1; w.split = 16;
-    RETURN_IF(gemm(w, T, s, BG_HEAD));
-    if (b.dropMask) {
-      hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)T * slab)), dim3(256), 0, s, dSeq, b.dropMask, dSeq, B, T,
-                         N, Np);
+    RETURN_IF(gemm(w, hT, s, BG_HEAD));
+    if (b.dropMask) {   // mask (B, hT, N, H) on the steps the head saw
+      hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)hT * slab)), dim3(256), 0, s, dSeq + (size_t)tOff * slab,
+                         b.dropMask, dSeq + (size_t)tOff * slab, B, hT, N, Np);
       CHECK_LAUNCH();
     }
   }
@@ -274,6 +280,77 @@ int backward_impl(Bwd& b, const float* dOut) {
     const float* WpU = tr + R.oWp[l][1];
     const float* RG = prm->res_gate[l].weight;     // (128, I)
     const float* RU = prm->res_update[l].weight;   // (64, I)
+    if (P.gcnOff) {
+      // ablation: the layer is one dense GRU cell per step on (x_t, h) (MultiATGCN.py:142-150,187-192,204); its
+      // nn.Linear parameters travel in the res_* fields.  z, r, hc were saved in the residual-cell slots.
+      float* carry[2] = {DH, DHa};
+      for (int t = T - 1; t >= 0; --t) {
+        const size_t at = (size_t)t * slab;
+        ChainArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dense = 1;
+        a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : carry[(t + 1) & 1];
+        a.hprev = t > 0 ? seq + at - slab : nullptr;
+        a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
+        a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR;
+        a.B = B; a.N = N; a.Np = Np; a.S = S;
+        const dim3 eg(blocks_for((size_t)slab));
+        hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
+        CHECK_LAUNCH();
+        GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
+        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
+        hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
+        CHECK_LAUNCH();
+        GemmArgs q2 = gemm_args(DPG2 + 2 * at, RG + C, carry[t & 1], B * Np, H, 128);
+        q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = H; q2.sCn = 1; q2.beta = 1.f;
+        RETURN_IF(gemm(q2, 1, s, BG_CHAIN_DENSE));
+      }
+      const float* Xall;
+      if (l == 0) {
+        float* X0tm = tr + R.oX0tm;
+        hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, s,
+                           c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
+        CHECK_LAUNCH();
+        Xall = X0tm;
+      } else {
+        Xall = c.ws + P.oSeq[l - 1];
+      }
+      float* Hprev = tr + R.oHprev; float* Z2H = tr + R.oZ2HA;
+      RETURN_IF(zero_async(Hprev, slab, s));
+      if (T > 1)
+        HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
+      const size_t seqN = (size_t)T * slab;
+      hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oZ2[l], Hprev, Z2H, seqN);
+      CHECK_LAUNCH();
+      float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
+      {
+        GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
+        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s, BG_X_NODE));
+        GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
+        q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
+        RETURN_IF(gemm(q2, 1, s, BG_X_NODE));
+      }
+      const matgcn_linear_grads& gg = g->res_gate[l];
+      const matgcn_linear_grads& gu = g->res_update[l];
+      if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
+      RETURN_IF(zero_async(gg.weight, 128L * I, s));
+      RETURN_IF(zero_async(gu.weight, 64L * I, s));
+      const long rows = (long)rowsTB * Np;
+      RETURN_IF(linear_weight_grad(b, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+      RETURN_IF(linear_weight_grad(b, DPG2, 128, Hprev, H, rows, I, C, gg.weight));
+      RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+      RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2H, H, rows, I, C, gu.weight));
+      RETURN_IF(zero_async(gg.bias, 128, s));
+      RETURN_IF(zero_async(gu.bias, 64, s));
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
+      CHECK_LAUNCH();
+      if (l > 0) cur ^= 1;
+      continue;
+    }
     // ---------------- chain ----------------
     for (int t = T - 1; t >= 0; --t) {
       const size_t at = (size_t)t * slab;
@@ -433,7 +510,7 @@ int backward_impl(Bwd& b, const float* dOut) {
   // ---- parameter-only part: node-adaptive weights -> pools, node_emb, weights_g (MultiATGCN.py:102-105) ----
   float* EK = tr + R.oEK; float* FK = tr + R.oFK; float* TmpK = tr + R.oTmpK; float* dgain = tr + R.oDGain;
   const int Kt = P.KtotOrig;
-  for (int l = 0; l < P.L; ++l)
+  for (int l = 0; l < P.L && !P.gcnOff; ++l)
     for (int part = 0; part < 2; ++part) {
       const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
       const matgcn_agcn_grads& ag = part == 0 ? g->gate[l] : g->update[l];
@@ -479,6 +556,25 @@ int backward_impl(Bwd& b, const float* dOut) {
 
   // ---- adaptive adjacency (MultiATGCN.py:80-83) ----
   if (adp) {
+    // Chebyshev orders of the adaptive adjacency A: T_o = 2 A T_{o-1} - T_{o-2} (MultiATGCN.py:98-99), back to A:
+    //   dA += 2 dT_o T_{o-1}^T;  dT_{o-1} += 2 A^T dT_o;  dT_{o-2} -= dT_o          (plain T_j = rows j*Np.. of StP)
+    const float* StP = tr + R.oStP;
+    const long NN = (long)N * N;
+    for (int o = P.per; o >= 2; --o) {
+      float* dTo = dT + (size_t)(o - 1) * NN;
+      const float* Tprev = StP + (size_t)(o - 2) * Np * P.NpC;
+      GemmArgs q = gemm_args(dTo, Tprev, dT, N, N, N);
+      q.sAm = N; q.sAk = 1; q.sBk = 1; q.sBn = P.NpC; q.sCm = N; q.sCn = 1; q.alpha = 2.f; q.beta = 1.f;
+      RETURN_IF(gemm(q, 1, s, BG_ADJ));
+      GemmArgs e = gemm_args(StP, dTo, dT + (size_t)(o - 2) * NN, N, N, N);
+      e.sAm = 1; e.sAk = P.NpC; e.sBk = N; e.sBn = 1; e.sCm = N; e.sCn = 1; e.alpha = 2.f; e.beta = 1.f;
+      RETURN_IF(gemm(e, 1, s, BG_ADJ));
+      if (o - 2 >= 1) {
+        hipLaunchKernelGGL(k_axpy, dim3(blocks_for((size_t)NN)), dim3(256), 0, s, dT + (size_t)(o - 3) * NN, dTo, -1.f,
+                           (size_t)NN);
+        CHECK_LAUNCH();
+      }
+    }
     const bool bi = D->adp_mode == MATGCN_ADP_BI;
     const int rank = bi ? D->embed_dim : D->adj_rank;
     float* dL = tr + R.oDL;
@@ -528,7 +624,6 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));
   const Plan& P = c.P;
-  if (dims->cheb_k > 2 || P.gcnOff || P.headT != P.T) return MATGCN_ERR_UNSUPPORTED;
   RETURN_IF(make_train_plan(P, &c.R));
   if (train_bytes < (size_t)c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   c.train = (float*)train;
@@ -537,10 +632,11 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
   const float* seqTop = c.ws + P.oSeq[P.L - 1];
-  if (drop_mask) {
+  if (drop_mask) {   // mask (B, headT, N, H) on the steps the head convolves (fnn_off: the last one)
+    const size_t ofs = (size_t)(P.T - P.headT) * P.B * P.Np * H;
     float* dropped = c.train + c.R.oSeqDrop;
-    hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)P.T * P.B * P.Np * H)), dim3(256), 0, c.s, seqTop,
-                       drop_mask, dropped, P.B, P.T, P.N, P.Np);
+    hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)P.headT * P.B * P.Np * H)), dim3(256), 0, c.s, seqTop + ofs,
+                       drop_mask, dropped + ofs, P.B, P.headT, P.N, P.Np);
     CHECK_LAUNCH();
     seqTop = dropped;
   }

@@ -285,17 +285,20 @@ struct ChainArgs {
   float* dh;             // running dh_{t-1}: written by part 3, completed by part 4 (becomes the next carry)
   float* dr;             // scratch [B][Np][64]
   int B, N, Np, S;
+  int dense;             // gcn_off: the layer IS a dense GRU cell on (x, h): "ha" is h_{t-1}, no blend (blend == null)
 };
 
 __device__ __forceinline__ float ha_of(const ChainArgs& a, size_t idx) {
-  const float h = a.hprev ? a.hprev[idx] : 0.f, r = a.r[idx];
+  const float h = a.hprev ? a.hprev[idx] : 0.f;
+  if (a.dense) return h;
+  const float r = a.r[idx];
   return r * h + (1.f - r) * a.hc[idx];
 }
 
 __global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
   __shared__ float red[256];
   const size_t total = (size_t)a.B * a.Np * 64;
-  const float g = sigmoid_f(a.blend[0]);
+  const float g = a.blend ? sigmoid_f(a.blend[0]) : 0.f;
   float part = 0.f;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int n = (idx >> 6) % a.Np;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
+  if (threadIdx.x == 0 && a.dblend) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
 }
 
 // part 2: gradient of z2*ha arrived -> dz2, dha += dzh2 * z2, gate pre-activation gradient of the residual cell
@@ -393,6 +396,13 @@ __global__ __launch_bounds__(256) void k_add_slot0(float* __restrict__ dst, cons
   if (idx >= rows * per) return;
   const size_t r = idx / per, q = idx - r * per;
   dst[idx] += src[r * S * per + q];
+}
+
+// dst += alpha * src
+__global__ __launch_bounds__(256) void k_axpy(float* __restrict__ dst, const float* __restrict__ src, float alpha,
+                                              size_t n) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < n) dst[idx] += alpha * src[idx];
 }
 
 // out[t][b][n][c] = a[t][b][n][c] * b[t][b][n][c]  (z * h_{t-1} for all steps)

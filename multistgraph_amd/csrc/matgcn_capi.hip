@@ -199,7 +199,7 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->oHprev = take(seq); R->oZH = take(seq); R->oHA = take(seq); R->oZ2HA = take(seq);
   R->oDAx = take(seq * R->S);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
-  R->oDT = take((long)P.N * P.N); R->oDL = take((long)P.N * P.N);
+  R->oDT = take((long)P.per * P.N * P.N); R->oDL = take((long)P.N * P.N);   // dT: one (N,N) per Chebyshev order
   R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
   R->oTmpK = take((long)P.KtotOrig * P.N * P.d); R->oDGain = take(64);
   R->oDOutRows = take((long)P.B * P.Np * P.CH);
@@ -338,6 +338,7 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -513,7 +514,14 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
         else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
         {
           ProfScope prof(MATGCN_PROF_RES, cs);
-          hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, cs, a);
+          const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
+          if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
+            const size_t at = (size_t)t * P.B * P.Np * H;
+            a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
+            hipLaunchKernelGGL((k_update16<2, true>), grid, dim3(512), P.nodeLds, cs, a);
+          } else {
+            hipLaunchKernelGGL((k_update16<2, false>), grid, dim3(512), P.nodeLds, cs, a);
+          }
         }
         CHECK_LAUNCH();
         if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));

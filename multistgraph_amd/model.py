@@ -247,14 +247,12 @@ class MultiATGCN(AbstractTrafficStateModel):
                                           "call model.eval() for inference")
             return self._path_for(x).forward(x)
         # training step: HIP forward that keeps its activations + HIP backward behind torch autograd
-        if self.gcn_off or self.fnn_off or self.cheb_order > 2:
-            raise NotImplementedError("the HIP backward is built for cheb_order = 2 without gcn_off / fnn_off "
-                                      "(DESIGN.md section 5c); this configuration can only run under no_grad")
         hp = self._path_for(x)
         mask = None
         if self.training:   # F.dropout(output, p=0.1) in front of end_conv (:416), drawn from torch's generator
-            mask = nn.functional.dropout(torch.ones(x.shape[0], self.input_window, self.num_nodes, self.hidden_dim,
-                                                    device=x.device), p=0.1, training=True)
+            mask = nn.functional.dropout(torch.ones(x.shape[0], 1 if self.fnn_off else self.input_window,
+                                                    self.num_nodes, self.hidden_dim, device=x.device),
+                                         p=0.1, training=True)   # fnn_off keeps the last step only (:412)
         named = list(self.named_parameters())
         return _TrainStep.apply(hp, x, mask, tuple(k for k, _ in named), *[p for _, p in named])
 

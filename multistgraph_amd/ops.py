@@ -287,7 +287,7 @@ class HotPath:
         if drop_mask is None:
             return None
         s = self.spec
-        return _check_tensor(drop_mask, "drop_mask", (self.batch, s.in_steps, s.nodes, s.hidden))
+        return _check_tensor(drop_mask, "drop_mask", (self.batch, 1 if s.fnn_off else s.in_steps, s.nodes, s.hidden))
 
     def forward_train(self, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """matgcn_forward that keeps the activations the backward needs (in the train buffer and the workspace).
@@ -322,27 +322,31 @@ class HotPath:
             grads[name] = t
             return t.data_ptr()
 
-        if state["node_emb"].requires_grad or not isinstance(state["node_emb"], torch.nn.Parameter):
-            g.node_emb = new("node_emb")
-        if s.adpadj == "unidirection":
-            g.node_vec1, g.node_vec2 = new("node_vec1"), new("node_vec2")
+        if not s.gcn_off:
+            if state["node_emb"].requires_grad or not isinstance(state["node_emb"], torch.nn.Parameter):
+                g.node_emb = new("node_emb")
+            if s.adpadj == "unidirection":
+                g.node_vec1, g.node_vec2 = new("node_vec1"), new("node_vec2")
+            g.weights_gru = new("encoder.weights_gru")
         g.weight_tsg = new("weight_tsg")
         for i in range(len(s.head_begin)):
             g.weight_ts[i] = new("weight_ts.%d" % i)
-        g.weights_gru = new("encoder.weights_gru")
         for l in range(s.layers):
-            for nm, dst in (("gate", g.gate), ("update", g.update)):
-                pre = "encoder.agru_cells.%d.%s." % (l, nm)
-                dst[l].weights_g = new(pre + "weights_g")
-                dst[l].weights_pool = new(pre + "weights_pool")
-                dst[l].bias_pool = new(pre + "bias_pool")
+            if not s.gcn_off:
+                for nm, dst in (("gate", g.gate), ("update", g.update)):
+                    pre = "encoder.agru_cells.%d.%s." % (l, nm)
+                    dst[l].weights_g = new(pre + "weights_g")
+                    dst[l].weights_pool = new(pre + "weights_pool")
+                    dst[l].bias_pool = new(pre + "bias_pool")
+            # gcn_off: encoder.agru_cells hold the dense GRU cells; they travel in the res_* fields (see bind)
+            cells = "encoder.agru_cells" if s.gcn_off else "encoder.res_cells"
             for nm, dst in (("gate", g.res_gate), ("update", g.res_update)):
-                pre = "encoder.res_cells.%d.%s." % (l, nm)
+                pre = "%s.%d.%s." % (cells, l, nm)
                 dst[l].weight = new(pre + "weight")
                 dst[l].bias = new(pre + "bias")
         g.end_conv_weight = new("end_conv.weight")
         g.end_conv_bias = new("end_conv.bias")
-        if not s.scale_by_g:      # the stack is not scaled: weights_g does not reach the output
+        if not s.scale_by_g and not s.gcn_off:   # the stack is not scaled: weights_g does not reach the output
             for l in range(s.layers):
                 for nm in ("gate", "update"):
                     grads["encoder.agru_cells.%d.%s.weights_g" % (l, nm)].zero_()

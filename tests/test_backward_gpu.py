@@ -15,7 +15,8 @@ from helpers import GOLDEN_DIR, TINY, Case, max_norm_err
 pytestmark = pytest.mark.gpu
 
 GRAD_TOL = 1e-4
-C2 = [n for n in TINY if n.endswith("_c2") or n.endswith("dyn7") or n.endswith("out12")]
+from helpers import FULL  # noqa: E402
+ABLATIONS = sorted(n for n in FULL if n.startswith("abl_"))
 
 
 def _path(c, fold=True):
@@ -99,10 +100,10 @@ def test_strided_batched_gemm(case, lib_built):
 
 
 @pytest.mark.parametrize("fold", [True, False])
-@pytest.mark.parametrize("name", C2)
+@pytest.mark.parametrize("name", TINY + ABLATIONS)
 def test_backward_matches_oracle_autograd(name, fold, lib_built):
     c = Case(name)
-    if not fold and c.adjtype not in ("multi", "cosine", "identity"):
+    if not fold and (c.adjtype not in ("multi", "cosine", "identity") or c.flags.get("gcn_off")):
         pytest.skip("no diagonal support to fold in this mode")
     hp, dev, state = _path(c, fold)
     rng = np.random.default_rng(c.seed + 11)
@@ -206,9 +207,30 @@ def test_plugin_training_step(name, lib_built, monkeypatch):
     assert float(l3) < float(l2)
 
 
-def test_training_refuses_unbuilt_configurations(lib_built):
-    from multistgraph_amd import _lib
-    c = Case("tiny_multi_uni_c3")
-    hp, dev, _ = _path(c)
-    with pytest.raises(_lib.MatgcnError):
-        hp.forward_train(torch.from_numpy(c.x).to(dev))
+def test_dropout_mask_of_the_last_step_head(lib_built):
+    """fnn_off: the head and its dropout see the last step only (MultiATGCN.py:412-416): mask (B, 1, N, H)"""
+    from oracle import matgcn_oracle as orc
+    c = Case("abl_fnnoff")
+    hp, dev, state = _path(c)
+    rng = np.random.default_rng(3)
+    mask = ((rng.random((c.b, 1, c.n, 64)) >= 0.1) / 0.9).astype(np.float32)
+    d_out = rng.standard_normal((c.b, c.out, c.n, 1)).astype(np.float32)
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in c.state.items()}
+    statics = orc.supports_as_tensors(c.gold["static_supports"], torch.float64)
+    cfg = c.oracle_cfg()
+    x0 = orc.fuse_heads(torch.tensor(c.x, dtype=torch.float64), p, cfg)
+    seq, _ = orc.encoder(x0, torch.zeros(2, c.b, c.n, 64, dtype=torch.float64), p, statics, cfg["adjtype"],
+                         cfg["adpadj"], cfg["cheb_order"], 2, faithful=False)
+    y = orc.output_head(seq[:, -1:] * torch.tensor(mask, dtype=torch.float64), p, c.out, 1)
+    (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
+    x = torch.from_numpy(c.x).to(dev)
+    tm = torch.from_numpy(mask).to(dev)
+    got_y = hp.forward_train(x, tm)
+    assert max_norm_err(got_y.cpu().numpy(), y.detach().numpy()) <= 1e-4
+    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state, tm)
+    for k, v in p.items():
+        w = v.grad.numpy() if v.grad is not None else np.zeros(v.shape)
+        if np.abs(w).max() == 0.0:
+            assert float(grads[k].abs().max()) <= 1e-6, k
+        else:
+            assert max_norm_err(grads[k].cpu().numpy(), w) <= GRAD_TOL, k
