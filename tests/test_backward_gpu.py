@@ -234,3 +234,65 @@ def test_dropout_mask_of_the_last_step_head(lib_built):
             assert float(grads[k].abs().max()) <= 1e-6, k
         else:
             assert max_norm_err(grads[k].cpu().numpy(), w) <= GRAD_TOL, k
+
+
+def _full_size(batch=64):
+    """Baltimore-size path (N = 403, multi + unidirection) with the golden case's parameters and a batch of 64"""
+    from multistgraph_amd.ops import HotPath, diagonal_mask, spec_from_config
+    c = Case("bm403_out24")
+    dev = torch.device("cuda:0")
+    st = torch.from_numpy(c.gold["static_supports"]).to(dev)
+    cfg = dict(c.config(), batch_size=batch)
+    spec = spec_from_config(cfg, c.data_feature, c.n, 20, st.shape[0], diagonal_mask(st))
+    hp = HotPath(spec, batch, dev)
+    state = {k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}
+    hp.bind(state, st)
+    rng = np.random.default_rng(5)
+    reps = (batch + c.b - 1) // c.b
+    x = np.tile(c.x, (reps, 1, 1, 1))[:batch].copy()
+    x[..., 0] += 0.05 * rng.standard_normal(x.shape[:-1]).astype(np.float32)
+    return c, hp, dev, state, torch.from_numpy(x).to(dev), rng
+
+
+def test_full_size_backward_is_linear_in_d_out(lib_built):
+    """size-independent property at BASELINE size (B=64, N=403): the backward is a linear map of d_out"""
+    c, hp, dev, state, x, rng = _full_size()
+    d1, d2 = (torch.from_numpy(rng.standard_normal((64, c.out, c.n, 1)).astype(np.float32)).to(dev) for _ in range(2))
+    hp.forward_train(x)
+    g1 = hp.backward(x, d1, state)
+    g2 = hp.backward(x, d2, state)
+    g3 = hp.backward(x, 0.5 * d1 - 2.0 * d2, state)
+    for k in g1:
+        want = (0.5 * g1[k].double() - 2.0 * g2[k].double()).cpu().numpy()
+        scale = max(float(g1[k].abs().max()), float(g2[k].abs().max()), 1e-30)
+        assert np.abs(g3[k].double().cpu().numpy() - want).max() <= 2e-4 * scale, k
+        assert torch.isfinite(g3[k]).all(), k
+
+
+def test_full_size_directional_derivative(lib_built):
+    """size-independent property at BASELINE size: <grad, v> equals the central difference of L = sum(out * d_out)
+    along random directions v of a few parameter tensors (fp32 forward: 2 % tolerance)"""
+    c, hp, dev, state, x, rng = _full_size()
+    d_out = torch.from_numpy(rng.standard_normal((64, c.out, c.n, 1)).astype(np.float32)).to(dev)
+    hp.forward_train(x)
+    grads = hp.backward(x, d_out, state)
+
+    def loss():
+        hp.prepare()
+        return float((hp.forward(x).double() * d_out.double()).sum())
+
+    for name in ("node_emb", "node_vec1", "encoder.agru_cells.1.gate.weights_pool", "encoder.weights_gru",
+                 "encoder.res_cells.0.update.weight", "weight_ts.0", "encoder.agru_cells.0.update.weights_g"):
+        p = state[name]
+        v = torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32)).to(dev)
+        eps = 2e-3 * float(p.abs().max()) / max(float(v.abs().max()), 1e-30) * 3.0
+        base = p.clone()
+        p.copy_(base + eps * v)
+        lp = loss()
+        p.copy_(base - eps * v)
+        lm = loss()
+        p.copy_(base)
+        fd = (lp - lm) / (2 * eps)
+        an = float((grads[name].double() * v.double()).sum())
+        assert abs(fd - an) <= 2e-2 * max(abs(an), abs(fd)) + 1e-3, (name, fd, an)
+    hp.prepare()
