@@ -204,7 +204,24 @@ int backward_impl(Bwd& b, const float* dOut) {
   // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
 
   // ---- scratch and outputs start from zero ----
-  RETURN_IF(zero_async(tr + R.keepFloats, R.floats - R.keepFloats, s));
+  // (only what is accumulated into, or what the GEMMs leave untouched: the rows of the padding nodes)
+  for (int l = 0; l < P.L; ++l)
+    for (int part = 0; part < 2; ++part) {
+      const long O = part == 0 ? 128 : 64, I = P.Cl[l] + H;
+      RETURN_IF(zero_async(tr + R.oDWp[l][part], (long)N * S * I * O, s));
+      RETURN_IF(zero_async(tr + R.oDBias[l][part], (long)N * O, s));
+    }
+  RETURN_IF(zero_async(tr + R.oDSeq[0], (long)T * slab, s));
+  RETURN_IF(zero_async(tr + R.oMixOut, slab, s));
+  RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
+  if (Np != N) {
+    float* padded[3] = {tr + R.oDAg, tr + R.oDAu, tr + R.oDAx};
+    for (float* buf : padded) {
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H)), dim3(256), 0, s, buf,
+                         rowsTB * S, N, Np, H);
+      CHECK_LAUNCH();
+    }
+  }
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
   RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
@@ -414,6 +431,11 @@ int backward_impl(Bwd& b, const float* dOut) {
     CHECK_LAUNCH();
     // x columns of both AGCNs -> gradient of the input sequence of this layer
     float* DAx = tr + R.oDAx;
+    if (C != H && Np != N) {   // narrower rows (layer 0): the padding rows sit elsewhere in the buffer
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * C)), dim3(256), 0, s, DAx,
+                         rowsTB * S, N, Np, C);
+      CHECK_LAUNCH();
+    }
     RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
     RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
     float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
