@@ -214,14 +214,15 @@ int backward_impl(Bwd& b, const float* dOut) {
   RETURN_IF(zero_async(tr + R.oDSeq[0], (long)T * slab, s));
   RETURN_IF(zero_async(tr + R.oMixOut, slab, s));
   RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
-  if (Np != N) {
-    float* padded[3] = {tr + R.oDAg, tr + R.oDAu, tr + R.oDAx};
-    for (float* buf : padded) {
-      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H)), dim3(256), 0, s, buf,
-                         rowsTB * S, N, Np, H);
-      CHECK_LAUNCH();
+  if (Np != N)
+    for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
+      float* padded[3] = {tr + R.oDAg[q], tr + R.oDAu[q], tr + R.oDAx[q]};
+      for (float* buf : padded) {
+        hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H)), dim3(256), 0, s, buf,
+                           rowsTB * S, N, Np, H);
+        CHECK_LAUNCH();
+      }
     }
-  }
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
   RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
@@ -285,13 +286,23 @@ int backward_impl(Bwd& b, const float* dOut) {
   }
 
   float* dT = tr + R.oDT;
+  // the weight gradients of a layer (big GEMMs) run on a library stream while the caller's stream already walks the
+  // chain of the layer below (small dependent launches); matgcn_set_wavefront(0) keeps everything on one stream
+  RETURN_IF(wavefront_ready());
+  const bool twoStreams = g_wavefront_mode != 0 && P.L > 1 && !P.gcnOff;
+  hipStream_t ws = twoStreams ? g_wf.chain[1] : s;
+  Bwd bw = b;
+  bw.c.s = ws;
   int cur = 0;
   for (int l = P.L - 1; l >= 0; --l) {
     const int C = P.Cl[l], I = C + H;
+    const int par = P.L > 1 ? (l & 1) : 0;
     const float* seq = c.ws + P.oSeq[l];
     float* dSeqCur = tr + R.oDSeq[cur];
-    float* DPU = tr + R.oDPU; float* DPG = tr + R.oDPG; float* DPU2 = tr + R.oDPU2; float* DPG2 = tr + R.oDPG2;
-    float* DAg = tr + R.oDAg; float* DAu = tr + R.oDAu;
+    if (twoStreams && l + 2 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 2], 0));   // scratch set is free again
+    float* DPU = tr + R.oDPU[par]; float* DPG = tr + R.oDPG[par];
+    float* DPU2 = tr + R.oDPU2[par]; float* DPG2 = tr + R.oDPG2[par];
+    float* DAg = tr + R.oDAg[par]; float* DAu = tr + R.oDAu[par];
     float* DH = tr + R.oDH; float* DHa = tr + R.oDHa; float* TMP = tr + R.oTmp; float* MixOut = tr + R.oMixOut;
     const float* WpG = tr + R.oWp[l][0];
     const float* WpU = tr + R.oWp[l][1];
@@ -333,7 +344,7 @@ int backward_impl(Bwd& b, const float* dOut) {
       } else {
         Xall = c.ws + P.oSeq[l - 1];
       }
-      float* Hprev = tr + R.oHprev; float* Z2H = tr + R.oZ2HA;
+      float* Hprev = tr + R.oHprev[par]; float* Z2H = tr + R.oZ2HA[par];
       RETURN_IF(zero_async(Hprev, slab, s));
       if (T > 1)
         HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -409,28 +420,8 @@ int backward_impl(Bwd& b, const float* dOut) {
       CHECK_LAUNCH();
     }
     // ---------------- everything that batches over the T steps ----------------
-    const float* Xall;
-    if (l == 0) {
-      float* X0tm = tr + R.oX0tm;
-      hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, s,
-                         c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
-      CHECK_LAUNCH();
-      Xall = X0tm;
-    } else {
-      Xall = c.ws + P.oSeq[l - 1];
-    }
-    float* Hprev = tr + R.oHprev; float* ZH = tr + R.oZH; float* HA = tr + R.oHA; float* Z2HA = tr + R.oZ2HA;
-    RETURN_IF(zero_async(Hprev, slab, s));
-    if (T > 1)
-      HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const size_t seqN = (size_t)T * slab;
-    hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oZ[l], Hprev, ZH, seqN);
-    CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oR[l], Hprev, tr + R.oHC[l],
-                       tr + R.oZ2[l], HA, Z2HA, seqN);
-    CHECK_LAUNCH();
     // x columns of both AGCNs -> gradient of the input sequence of this layer
-    float* DAx = tr + R.oDAx;
+    float* DAx = tr + R.oDAx[par];
     if (C != H && Np != N) {   // narrower rows (layer 0): the padding rows sit elsewhere in the buffer
       hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * C)), dim3(256), 0, s, DAx,
                          rowsTB * S, N, Np, C);
@@ -452,39 +443,65 @@ int backward_impl(Bwd& b, const float* dOut) {
       q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
       RETURN_IF(gemm(q2, 1, s));
     }
+    // ---- from here on: the layer's weight gradients, on the second stream ----
+    if (twoStreams) {
+      HIP_OK(hipEventRecord(g_wf.step[0][l], s));
+      HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
+    }
+    const float* Xall;
+    if (l == 0) {
+      float* X0tm = tr + R.oX0tm;
+      hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, ws,
+                         c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
+      CHECK_LAUNCH();
+      Xall = X0tm;
+    } else {
+      Xall = c.ws + P.oSeq[l - 1];
+    }
+    float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
+    float* Z2HA = tr + R.oZ2HA[par];
+    RETURN_IF(zero_async(Hprev, slab, ws));
+    if (T > 1)
+      HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
+    const size_t seqN = (size_t)T * slab;
+    hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oZ[l], Hprev, ZH, seqN);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oR[l], Hprev, tr + R.oHC[l],
+                       tr + R.oZ2[l], HA, Z2HA, seqN);
+    CHECK_LAUNCH();
     // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
     float* dWpG = tr + R.oDWp[l][0];
     float* dWpU = tr + R.oDWp[l][1];
     const long gStep = (long)N * B * P.Ks * H;
     {  // recurrent rows: [T][N][B][Ks][64]
       MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
-      RETURN_IF(node_weight_grad(b, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
+      RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
       MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
-      RETURN_IF(node_weight_grad(b, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
+      RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
     }
     if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
       const long ld = rup((long)rowsTB * P.C0, 64);
       MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
-      RETURN_IF(node_weight_grad(b, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
-      RETURN_IF(node_weight_grad(b, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
     } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
       for (int t0 = 0; t0 < T;) {
         const int nt = chunk_steps(P, t0);
         MixedRows mx = {tr + R.oGX[l] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, nt * B};
-        RETURN_IF(node_weight_grad(b, Xall, mx, C, DPG, 128, I, 0, (long)t0 * B, nt * B, dWpG));
-        RETURN_IF(node_weight_grad(b, Xall, mx, C, DPU, 64, I, 0, (long)t0 * B, nt * B, dWpU));
+        RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, (long)t0 * B, nt * B, dWpG));
+        RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, (long)t0 * B, nt * B, dWpU));
         t0 += nt;
       }
     }
     if (adp) {
-      RETURN_IF(adaptive_grad(b, DAx, Xall, rowsTB, C, dT));
-      RETURN_IF(adaptive_grad(b, DAg, Hprev, rowsTB, H, dT));
-      RETURN_IF(adaptive_grad(b, DAu, ZH, rowsTB, H, dT));
+      RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
+      RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
+      RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
     }
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, s, DPG, (size_t)rowsTB, N,
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
                        Np, 128, tr + R.oDBias[l][0]);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, s, DPU, (size_t)rowsTB, N, Np,
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
                        64, tr + R.oDBias[l][1]);
     CHECK_LAUNCH();
     // residual nn.Linear gradients (MultiATGCN.py:139-150)
@@ -492,22 +509,25 @@ int backward_impl(Bwd& b, const float* dOut) {
       const matgcn_linear_grads& gg = g->res_gate[l];
       const matgcn_linear_grads& gu = g->res_update[l];
       if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
-      RETURN_IF(zero_async(gg.weight, 128L * I, s));
-      RETURN_IF(zero_async(gu.weight, 64L * I, s));
+      RETURN_IF(zero_async(gg.weight, 128L * I, ws));
+      RETURN_IF(zero_async(gu.weight, 64L * I, ws));
       const long rows = (long)rowsTB * Np;
-      RETURN_IF(linear_weight_grad(b, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
-      RETURN_IF(linear_weight_grad(b, DPG2, 128, HA, H, rows, I, C, gg.weight));
-      RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
-      RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
-      RETURN_IF(zero_async(gg.bias, 128, s));
-      RETURN_IF(zero_async(gu.bias, 64, s));
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
+      RETURN_IF(linear_weight_grad(bw, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+      RETURN_IF(linear_weight_grad(bw, DPG2, 128, HA, H, rows, I, C, gg.weight));
+      RETURN_IF(linear_weight_grad(bw, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+      RETURN_IF(linear_weight_grad(bw, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
+      RETURN_IF(zero_async(gg.bias, 128, ws));
+      RETURN_IF(zero_async(gu.bias, 64, ws));
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
       CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
+      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
       CHECK_LAUNCH();
     }
+    if (twoStreams) HIP_OK(hipEventRecord(g_wf.step[1][l], ws));
     if (l > 0) cur ^= 1;
   }
+  if (twoStreams)
+    for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l], 0));   // join
 
   // ---- head fusion (MultiATGCN.py:365-402) ----
   {

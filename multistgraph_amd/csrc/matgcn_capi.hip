@@ -156,11 +156,13 @@ struct TrainPlan {
   long oGH[MATGCN_MAX_LAYERS], oGZH[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS];
   long keepFloats;                         // [keepFloats, floats) is zeroed by backward
   long oWp[MATGCN_MAX_LAYERS][2], oDWp[MATGCN_MAX_LAYERS][2], oDBias[MATGCN_MAX_LAYERS][2];
-  long oDPU, oDPG, oDPU2, oDPG2;           // pre-activation gradients of every step
+  // per-layer scratch exists twice (index l & 1): the weight gradients of layer l run on a second stream while the
+  // chain of layer l-1 already fills the other set
+  long oDPU[2], oDPG[2], oDPU2[2], oDPG2[2];   // pre-activation gradients of every step
   long oDSeq[2];                           // gradient of a layer's output sequence (ping-pong)
-  long oDAg, oDAu;                         // [T][B][S][Np][64] gradient of [s | mix(s)] of both AGCNs, h columns
+  long oDAg[2], oDAu[2], oDAx[2];          // [T][B][S][Np][C] gradient of [s | mix(s)] of both AGCNs (h / x columns)
   long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
-  long oX0tm, oHprev, oZH, oHA, oZ2HA, oDAx, oDX0;
+  long oX0tm, oHprev[2], oZH[2], oHA[2], oZ2HA[2], oDX0;
   long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
   long oStP;                               // [Ks*Np][NpC] plain support stack (A operand of the transposed mix)
   long floats;
@@ -191,13 +193,14 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
       R->oDWp[l][part] = take((long)P.N * R->S * I * O);
       R->oDBias[l][part] = take((long)P.N * O);
     }
-  R->oDPU = take(seq); R->oDPG = take(2 * seq); R->oDPU2 = take(seq); R->oDPG2 = take(2 * seq);
+  for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
+    R->oDPU[q] = take(seq); R->oDPG[q] = take(2 * seq); R->oDPU2[q] = take(seq); R->oDPG2[q] = take(2 * seq);
+    R->oDAg[q] = take(seq * R->S); R->oDAu[q] = take(seq * R->S); R->oDAx[q] = take(seq * R->S);
+    R->oHprev[q] = take(seq); R->oZH[q] = take(seq); R->oHA[q] = take(seq); R->oZ2HA[q] = take(seq);
+  }
   R->oDSeq[0] = take(seq); R->oDSeq[1] = take(seq);
-  R->oDAg = take(seq * R->S); R->oDAu = take(seq * R->S);
   R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab); R->oMixOut = take(slab);
   R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
-  R->oHprev = take(seq); R->oZH = take(seq); R->oHA = take(seq); R->oZ2HA = take(seq);
-  R->oDAx = take(seq * R->S);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
   R->oDT = take((long)P.per * P.N * P.N); R->oDL = take((long)P.N * P.N);   // dT: one (N,N) per Chebyshev order
   R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
