@@ -124,3 +124,24 @@ def test_diagonal_supports_are_detected_on_the_host():
     assert diagonal_mask(None) == 0
     ci = Case("tiny_identity_non_c2")
     assert MultiATGCN(ci.config(), ci.data_feature).spec.diag_static_mask == 1
+
+
+def test_training_entry_points_check_their_arguments(lib_built):
+    # no GPU needed: size query and the argument checks that come before any launch
+    from multistgraph_amd import _lib
+    from multistgraph_amd.ops import spec_from_config
+    lib = _lib.load()
+    c = Case("bm403_out24")
+    spec = spec_from_config(c.config(), c.data_feature, c.n, 20, 3)
+    d = spec.dims(64)
+    nb = C.c_size_t()
+    assert lib.matgcn_train_bytes(C.byref(d), C.byref(nb)) == 0
+    assert 8e9 < nb.value < 16e9          # saved activations + mixed rows + two scratch sets at B=64, N=403
+    d1 = spec.dims(1)
+    nb1 = C.c_size_t()
+    assert lib.matgcn_train_bytes(C.byref(d1), C.byref(nb1)) == 0 and nb1.value < nb.value / 20
+    assert lib.matgcn_train_bytes(C.byref(d), None) == -1
+    p = _lib.Params()
+    assert lib.matgcn_forward_train(C.byref(d), C.byref(p), None, None, None, None, None, 0, None, 0, None) == -1
+    assert lib.matgcn_backward(C.byref(d), C.byref(p), None, None, None, None, C.byref(p), None, 0, None, 0, None) == -1
+    assert lib.matgcn_debug_gemm(None, None, None, None, 1.0, 0.0, None) == -1
