@@ -289,6 +289,15 @@ int backward_impl(Bwd& b, const float* dOut) {
   // the weight gradients of a layer (big GEMMs) run on a library stream while the caller's stream already walks the
   // chain of the layer below (small dependent launches); matgcn_set_wavefront(0) keeps everything on one stream
   RETURN_IF(wavefront_ready());
+  const int fusedLds = 128 * CF_LD * (int)sizeof(float);
+  {
+    static bool optedIn = false;   // dynamic LDS above 64 KB must be opted into once
+    if (!optedIn) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, fusedLds));
+      optedIn = true;
+    }
+  }
   const bool twoStreams = g_wavefront_mode != 0 && P.L > 1 && !P.gcnOff;
   hipStream_t ws = twoStreams ? g_wf.chain[1] : s;
   Bwd bw = b;
@@ -394,30 +403,22 @@ int backward_impl(Bwd& b, const float* dOut) {
       a.dh = DH; a.dr = tr + R.oDR;
       a.B = B; a.N = N; a.Np = Np; a.S = S;
       const dim3 eg(blocks_for((size_t)slab));
-      hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
-      CHECK_LAUNCH();
-      {  // gradient of z2*ha = dpre_u2 . RU[:, C:]
-        GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
-        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
+      {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
+        FusedResArgs f;
+        f.c = a;
+        f.c.dcarry = (t == T - 1) ? nullptr : DH;
+        f.carryA = (t == T - 1) ? nullptr : DAg + (at + slab) * S;
+        f.carryMix = (t == T - 1 || P.Ks <= 0) ? nullptr : MixOut;
+        f.ruh = RU + C; f.rgh = RG + C; f.ldW = I;
+        hipLaunchKernelGGL(k_chain_res_fused, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
+        CHECK_LAUNCH();
       }
-      hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
-      CHECK_LAUNCH();
-      {  // dha += dpre_g2 . RG[:, C:]
-        GemmArgs q = gemm_args(DPG2 + 2 * at, RG + C, DHa, B * Np, H, 128);
-        q.sAm = 128; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1; q.beta = 1.f;
-        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
-      }
-      hipLaunchKernelGGL(k_chain_cell_out, eg, dim3(256), 0, s, a);
-      CHECK_LAUNCH();
       RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
       RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
       hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
       CHECK_LAUNCH();
       RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, 0.f));
-      RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));
-      hipLaunchKernelGGL(k_chain_carry, eg, dim3(256), 0, s, a);
-      CHECK_LAUNCH();
+      RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
     }
     // ---------------- everything that batches over the T steps ----------------
     // x columns of both AGCNs -> gradient of the input sequence of this layer

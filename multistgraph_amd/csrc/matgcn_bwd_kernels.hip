@@ -320,6 +320,165 @@ __global__ __launch_bounds__(256) void k_chain_res_out(ChainArgs a) {
   if (threadIdx.x == 0 && a.dblend) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
 }
 
+// ---- parts 1-3 (and the carry of the step before) in one kernel -------------------------------------------------
+// Everything between the incoming gradient of h'_t and the pre-activation gradient of the update AGCN is local to a
+// row (b, n): blend, residual-cell algebra, the two nn.Linear contractions with the h columns of the residual
+// weights (shared by all rows: staged in LDS), graph-cell output algebra.  One workgroup owns 64 rows; the two
+// contractions run on the 16x16x4 MFMA with the A tile (the freshly computed pre-activation gradients) in LDS.
+//   incoming: dseq (+ carry of step t+1 = dh + slot 0 of the gate AGCN's dA + its transposed mix)
+//   outgoing: dpu2, dpg2 (kept for the batched part), dpu (update AGCN), dr, dh (partial), blend-scalar gradient
+#define CF_LD 80
+struct FusedResArgs {
+  ChainArgs c;
+  const float* carryA;   // dA of the gate AGCN of step t+1 ([B][S][Np][64], slot 0 is read) or null
+  const float* carryMix; // its transposed mix [B][Np][64] or null
+  const float* ruh;      // RU + C: RU[o][C + i] at ruh[o*ldW + i]
+  const float* rgh;      // RG + C
+  int ldW;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
+__device__ __forceinline__ float get4(const float4& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : x == 2 ? v.z : v.w; }
+
+__global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ps = lds;                    // [128 k][CF_LD] k-major A tile (element (k, local row)); the weights (B operands,
+                                      // 48 KB shared by all workgroups) come straight from L2 so that several
+                                      // workgroups fit a CU
+  __shared__ float red[256];
+  const ChainArgs& a = f.c;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const size_t rows = (size_t)a.B * a.Np, row0 = (size_t)blockIdx.x * 64;
+  const float g = sigmoid_f(a.blend[0]);
+  // phase 1 (one thread per row and 4 columns, 16-byte accesses): everything that does not need a contraction -
+  // dpu2 and the r half of dpg2 -> global + A tile; dha so far and ha*z2*(1-z2) -> row scratch; blend partial sum
+  float part = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = tid + 256 * it, lr = q >> 4, c4 = (q & 15) * 4;
+    float dpu2[4] = {0.f, 0.f, 0.f, 0.f}, drr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + lr < rows) {
+      const size_t row = row0 + lr, idx = row * 64 + c4;
+      float4 dhp = ld4(a.dseq, idx);
+      if (a.dcarry) {
+        const size_t b = row / a.Np, n = row - b * a.Np;
+        const float4 c0 = ld4(a.dcarry, idx), c1 = ld4(f.carryA, ((b * a.S) * a.Np + n) * 64 + c4);
+        dhp = make_float4(dhp.x + c0.x + c1.x, dhp.y + c0.y + c1.y, dhp.z + c0.z + c1.z, dhp.w + c0.w + c1.w);
+        if (f.carryMix) {
+          const float4 c2 = ld4(f.carryMix, idx);
+          dhp = make_float4(dhp.x + c2.x, dhp.y + c2.y, dhp.z + c2.z, dhp.w + c2.w);
+        }
+      }
+      const float4 hp = a.hprev ? ld4(a.hprev, idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r4 = ld4(a.r, idx), hc4 = ld4(a.hc, idx), r24 = ld4(a.r2, idx), z24 = ld4(a.z2, idx);
+      const float4 hc24 = ld4(a.hc2, idx);
+      float dha0[4], c1v[4];
+      const bool real = (int)(row % a.Np) < a.N;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float d = get4(dhp, x), h = get4(hp, x), r = get4(r4, x), hc = get4(hc4, x);
+        const float r2 = get4(r24, x), z2 = get4(z24, x), hc2 = get4(hc24, x);
+        const float ha = r * h + (1.f - r) * hc;
+        const float res = r2 * ha + (1.f - r2) * hc2;
+        if (real) part += d * (ha - res);
+        const float dres = (1.f - g) * d;
+        dha0[x] = g * d + dres * r2;
+        dpu2[x] = dres * (1.f - r2) * (1.f - hc2 * hc2);
+        drr[x] = dres * (ha - hc2) * r2 * (1.f - r2);
+        c1v[x] = ha * z2 * (1.f - z2);
+      }
+      *reinterpret_cast<float4*>(a.dpu2 + idx) = make_float4(dpu2[0], dpu2[1], dpu2[2], dpu2[3]);
+      *reinterpret_cast<float4*>(a.dpg2 + row * 128 + 64 + c4) = make_float4(drr[0], drr[1], drr[2], drr[3]);
+      *reinterpret_cast<float4*>(a.dha + idx) = make_float4(dha0[0], dha0[1], dha0[2], dha0[3]);
+      *reinterpret_cast<float4*>(const_cast<float*>(a.dzh2) + idx) = make_float4(c1v[0], c1v[1], c1v[2], c1v[3]);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      Ps[(c4 + x) * CF_LD + lr] = dpu2[x];
+      Ps[(64 + c4 + x) * CF_LD + lr] = drr[x];
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
+  // phase 2: d(z2*ha) = dpu2 . RU[:, C:]
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int s = 0; s < 16; ++s) {
+    const int k = 4 * s + kq;
+    float av[2], bv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) av[p] = Ps[k * CF_LD + wm * 32 + p * 16 + j];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bv[q] = f.ruh[(size_t)k * f.ldW + wn * 32 + q * 16 + j];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[p][q] = MFMA16(av[p], bv[q], acc[p][q]);
+  }
+  __syncthreads();   // every wave is done reading the dpu2 rows of the tile
+  // phase 3: the z half of dpg2 -> global + A tile; dha so far moves into the accumulators of the second contraction
+  // (the row scratch written in phase 1 is read back by other threads of this workgroup: ordered by the barriers)
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int lr = wm * 32 + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
+        float dz = 0.f, dha = 0.f;
+        if (row0 + lr < rows) {
+          const size_t idx = (row0 + lr) * 64 + col;
+          const float dzh2 = acc[p][q][e4];
+          dha = a.dha[idx] + dzh2 * a.z2[idx];
+          dz = dzh2 * a.dzh2[idx];
+          a.dpg2[(row0 + lr) * 128 + col] = dz;
+        }
+        Ps[col * CF_LD + lr] = dz;
+        acc[p][q][e4] = dha;
+      }
+  __syncthreads();
+  // phase 4: dha += dpg2 . RG[:, C:]
+#pragma unroll 8
+  for (int s = 0; s < 32; ++s) {
+    const int k = 4 * s + kq;
+    float av[2], bv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) av[p] = Ps[k * CF_LD + wm * 32 + p * 16 + j];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bv[q] = f.rgh[(size_t)k * f.ldW + wn * 32 + q * 16 + j];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[p][q] = MFMA16(av[p], bv[q], acc[p][q]);
+  }
+  // phase 5: graph cell output algebra (MultiATGCN.py:127)
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int lr = wm * 32 + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
+        if (row0 + lr >= rows) continue;
+        const size_t idx = (row0 + lr) * 64 + col;
+        const float dha = acc[p][q][e4];
+        const float h = a.hprev ? a.hprev[idx] : 0.f, r = a.r[idx], hc = a.hc[idx];
+        a.dr[idx] = dha * (h - hc);
+        a.dh[idx] = dha * r;
+        a.dpu[idx] = dha * (1.f - r) * (1.f - hc * hc);
+      }
+}
+
 // part 2: gradient of z2*ha arrived -> dz2, dha += dzh2 * z2, gate pre-activation gradient of the residual cell
 __global__ __launch_bounds__(256) void k_chain_res_gate(ChainArgs a) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
