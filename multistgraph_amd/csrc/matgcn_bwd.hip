@@ -112,14 +112,17 @@ int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst)
 }
 
 // dA[rows][s][n][i] (+)= dPre[rows][n][0:O] . Wp[n][s][iOfs + i][0:O]^T for every node and slot
+// (nodeMajor: dA is laid out [s][n][rows][Cc] instead - used for the narrow x columns of layer 0, whose transposed
+// mix then is ONE GEMM with rows*Cc columns instead of `rows` GEMMs with Cc columns)
 int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp, int I, int iOfs, int Cc, int rows,
-                         float* dA, float beta) {
+                         float* dA, float beta, bool nodeMajor = false) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
   GemmArgs g = gemm_args(dPre, Wp + (size_t)iOfs * O, dA, rows, Cc, O);
   g.sAm = (long)P.Np * O; g.sAk = 1; g.bA1 = O;
   g.sBk = 1; g.sBn = O; g.bB1 = (long)S * I * O; g.bB2 = (long)I * O;
   g.sCm = (long)S * P.Np * Cc; g.sCn = 1; g.bC1 = Cc; g.bC2 = (long)P.Np * Cc;
+  if (nodeMajor) { g.sCm = Cc; g.bC1 = (long)rows * Cc; g.bC2 = (long)P.Np * rows * Cc; }
   g.nb2 = S; g.beta = beta;
   return gemm(g, P.N, b.c.s, rows > P.B ? BG_X_NODE : BG_CHAIN_NODE);
 }
@@ -160,13 +163,15 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
 
 // dT_j[n][m] += sum_{rows, i} dA[rows][slot 1 + j][n][i] * U[rows][m][i] for the `per` Chebyshev orders of the adaptive
 // adjacency (first-order support 0 is never diagonal: its orders are the dense slots 0 .. per-1)
-int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int Cc, float* dT) {
+int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int Cc, float* dT, bool nodeMajor = false) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
   for (int j = 0; j < P.per; ++j) {
-    GemmArgs g = gemm_args(dA + (size_t)(1 + j) * P.Np * Cc, U, dT + (size_t)j * P.N * P.N, P.N, P.N, Cc);
+    const size_t slot = nodeMajor ? (size_t)(1 + j) * P.Np * rows * Cc : (size_t)(1 + j) * P.Np * Cc;
+    GemmArgs g = gemm_args(dA + slot, U, dT + (size_t)j * P.N * P.N, P.N, P.N, Cc);
     g.K2 = rows;
     g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;
+    if (nodeMajor) { g.sAm = (long)rows * Cc; g.sAk2 = Cc; }
     g.sBk = 1; g.sBn = Cc; g.sBk2 = (long)P.Np * Cc;
     g.sCm = P.N; g.sCn = 1;
     g.mode = 1; g.split = 48;
@@ -423,19 +428,32 @@ int backward_impl(Bwd& b, const float* dOut) {
     // ---------------- everything that batches over the T steps ----------------
     // x columns of both AGCNs -> gradient of the input sequence of this layer
     float* DAx = tr + R.oDAx[par];
-    if (C != H && Np != N) {   // narrower rows (layer 0): the padding rows sit elsewhere in the buffer
-      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * C)), dim3(256), 0, s, DAx,
-                         rowsTB * S, N, Np, C);
+    const bool narrow = C != H;   // layer 0: a handful of input channels
+    float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
+    if (narrow) {
+      // node-major [s][n][rows][C]: the transposed mix is one GEMM with rows*C columns
+      RETURN_IF(zero_async(DAx, (long)rowsTB * S * Np * C, s));
+      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f, true));
+      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f, true));
+      const long cols = (long)rowsTB * C;
+      float* MixN = tr + R.oMixN;
+      if (P.Ks > 0) {
+        GemmArgs q = gemm_args(c.prep + P.oSt, DAx + (size_t)Np * cols, MixN, N, (int)cols, P.Ks * Np);
+        q.sAm = P.Mp; q.sAk = 1; q.sBk = cols; q.sBn = 1; q.sCm = cols; q.sCn = 1;
+        RETURN_IF(gemm(q, 1, s, BG_X_MIX));
+      }
+      hipLaunchKernelGGL(k_narrow_gather, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s,
+                         P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
+      CHECK_LAUNCH();
+    } else {
+      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
+      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
+      RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
+      RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
+      hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
+                         (size_t)rowsTB, Np, C, S);
       CHECK_LAUNCH();
     }
-    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
-    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
-    float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
-    RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
-    RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
-    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
-                       (size_t)rowsTB, Np, C, S);
-    CHECK_LAUNCH();
     {  // residual cell x columns
       GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
       q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
@@ -495,7 +513,7 @@ int backward_impl(Bwd& b, const float* dOut) {
       }
     }
     if (adp) {
-      RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
+      RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, narrow));
       RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
       RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
     }

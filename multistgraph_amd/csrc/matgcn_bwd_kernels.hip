@@ -282,7 +282,8 @@ struct ChainArgs {
   const float* dzhMix;   // transposed-mix result [B][Np][64] (null when Ks = 0)
   const float* dhA;      // dA buffer of the gate AGCN
   const float* dhMix;
-  float* dh;             // running dh_{t-1}: written by part 3, completed by part 4 (becomes the next carry)
+  float* dh;             // running dh_{t-1}: written by part 3, extended by part 4; the next step's fused kernel adds
+                         // slot 0 of the gate AGCN's dA and its transposed mix to form the carry
   float* dr;             // scratch [B][Np][64]
   int B, N, Np, S;
   int dense;             // gcn_off: the layer IS a dense GRU cell on (x, h): "ha" is h_{t-1}, no blend (blend == null)
@@ -516,18 +517,6 @@ __global__ __launch_bounds__(256) void k_chain_cell_gate(ChainArgs a) {
   a.dpg[row * 128 + 64 + o] = a.dr[idx] * r * (1.f - r);
 }
 
-// part 5: gradient of h from the gate AGCN arrived: dh_{t-1} complete
-__global__ __launch_bounds__(256) void k_chain_carry(ChainArgs a) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)a.B * a.Np * 64) return;
-  const size_t row = idx >> 6;
-  const int o = idx & 63;
-  const size_t b = row / a.Np, n = row - b * a.Np;
-  float v = a.dh[idx] + a.dhA[((b * a.S) * a.Np + n) * 64 + o];
-  if (a.dhMix) v += a.dhMix[idx];
-  a.dh[idx] = v;
-}
-
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
@@ -555,6 +544,18 @@ __global__ __launch_bounds__(256) void k_add_slot0(float* __restrict__ dst, cons
   if (idx >= rows * per) return;
   const size_t r = idx / per, q = idx - r * per;
   dst[idx] += src[r * S * per + q];
+}
+
+// narrow x columns (layer 0): dst[row][n][c] = mix[n][row*C + c] + slot0[n][row*C + c]  (node-major -> row-major)
+__global__ __launch_bounds__(256) void k_narrow_gather(const float* __restrict__ mix, const float* __restrict__ slot0,
+                                                       float* __restrict__ dst, size_t rows, int N, int Np, int C) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * Np * C) return;
+  const int c = idx % C;
+  const int n = (idx / C) % Np;
+  const size_t row = idx / ((size_t)C * Np);
+  const size_t src = ((size_t)n * rows + row) * C + c;
+  dst[idx] = n < N ? (mix ? mix[src] : 0.f) + slot0[src] : 0.f;
 }
 
 // dst += alpha * src

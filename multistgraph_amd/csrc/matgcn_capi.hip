@@ -163,6 +163,7 @@ struct TrainPlan {
   long oDAg[2], oDAu[2], oDAx[2];          // [T][B][S][Np][C] gradient of [s | mix(s)] of both AGCNs (h / x columns)
   long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
   long oX0tm, oHprev[2], oZH[2], oHA[2], oZ2HA[2], oDX0;
+  long oMixN;                              // [Np][T*B*C0] transposed mix of the narrow layer-0 x columns
   long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
   long oStP;                               // [Ks*Np][NpC] plain support stack (A operand of the transposed mix)
   long floats;
@@ -202,6 +203,7 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab); R->oMixOut = take(slab);
   R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
+  R->oMixN = take((long)P.T * P.B * P.Np * P.C0);
   R->oDT = take((long)P.per * P.N * P.N); R->oDL = take((long)P.N * P.N);   // dT: one (N,N) per Chebyshev order
   R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
   R->oTmpK = take((long)P.KtotOrig * P.N * P.d); R->oDGain = take(64);
