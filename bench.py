@@ -127,15 +127,18 @@ def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     return out
 
 
-def train_step_times(model, batch, w, warm=2, steps=5):
+def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None):
     """One optimisation step as TrafficStateExecutor._train_epoch runs it (traffic_state_executor.py:411-422):
     loss = model.calculate_loss(batch); loss.backward(); optimizer.step() - forward_train + backward on the HIP
-    path, Adam in torch.  Reported beside the headline; runs last because it moves the weights."""
+    path, Adam in torch.  With more than one rank every rank steps on its own batch shard and the
+    gradients meet in ONE flat-bucket all-reduce (RCCL over xGMI) before the optimizer, as BASELINE config 4 asks.
+    Reported beside the headline; runs last because it moves the weights."""
+    from multistgraph_amd import sharding
     model.train()
     model.cache_prepared = True
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    fwd, bwd, adam, losses = [], [], [], []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    fwd, bwd, red, adam, losses = [], [], [], [], []
     for i in range(warm + steps):
         opt.zero_grad()
         ev[0].record()
@@ -143,19 +146,29 @@ def train_step_times(model, batch, w, warm=2, steps=5):
         ev[1].record()
         loss.backward()
         ev[2].record()
-        opt.step()
+        if world > 1:
+            sharding.flat_allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
         ev[3].record()
+        opt.step()
+        ev[4].record()
         torch.cuda.synchronize()
         losses.append(float(loss.detach()))
         if i >= warm:
-            fwd.append(ev[0].elapsed_time(ev[1])); bwd.append(ev[1].elapsed_time(ev[2])); adam.append(ev[2].elapsed_time(ev[3]))
+            fwd.append(ev[0].elapsed_time(ev[1])); bwd.append(ev[1].elapsed_time(ev[2]))
+            red.append(ev[2].elapsed_time(ev[3])); adam.append(ev[3].elapsed_time(ev[4]))
     model.eval()
-    total = statistics.mean(fwd) + statistics.mean(bwd) + statistics.mean(adam)
-    return {"forward_ms": statistics.mean(fwd), "backward_ms": statistics.mean(bwd), "optimizer_ms": statistics.mean(adam),
-            "ms_per_step": total, "node_steps_per_s": w["batch"] * 24 * w["nodes"] / (total * 1e-3), "steps": steps,
-            "loss_first": losses[0], "loss_last": losses[-1],
-            "note": "training step through the plugin surface: HIP forward that keeps activations (incl. the prepare "
-                    "after every weight update) + HIP backward behind torch autograd + torch Adam; dropout p=0.1 on"}
+    total = statistics.mean(fwd) + statistics.mean(bwd) + statistics.mean(red) + statistics.mean(adam)
+    out = {"forward_ms": statistics.mean(fwd), "backward_ms": statistics.mean(bwd),
+           "grad_allreduce_ms": statistics.mean(red) if world > 1 else None, "optimizer_ms": statistics.mean(adam),
+           "ms_per_step": total, "node_steps_per_s": world * w["batch"] * 24 * w["nodes"] / (total * 1e-3),
+           "steps": steps, "loss_first": losses[0], "loss_last": losses[-1],
+           "note": "training step through the plugin surface, rank 0's clock: HIP forward that keeps activations "
+                   "(incl. the prepare after every weight update) + HIP backward behind torch autograd "
+                   "(+ one flat-bucket gradient all-reduce when n_gpus > 1) + torch Adam; dropout p=0.1 on"}
+    if world > 1:
+        out["grad_bucket_mb"] = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4 / 1e6
+        out["replicas_in_sync"] = sharding.replicas_in_sync(model.parameters(), device=device)
+    return out
 
 
 def main():
@@ -180,11 +193,19 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     distributed = world > 1
+    # rehearsal knobs (a 2-rank dry run of the multi-rank code path on a ONE-GPU box): every rank on device 0 and
+    # gloo instead of RCCL; never set by the driver
+    if os.environ.get("MATGCN_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MATGCN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from multistgraph_amd import build as mbuild
     from multistgraph_amd import synthetic as syn
@@ -319,6 +340,15 @@ def main():
             result["gpu_over_cpu"] = value / base["value"]
         if world == 1 and not args.no_train_step:
             result["train_step"] = train_step_times(model, batch, w)
+    if distributed and not args.no_train_step:
+        # every rank takes part (the gradient all-reduce is a collective); rank 0 reports
+        try:
+            ts = train_step_times(model, batch, w, world=world, device=device)
+        except Exception as exc:   # noqa: BLE001 - the headline line must survive a failure of the optional section
+            ts = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0:
+            result["train_step"] = ts
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()

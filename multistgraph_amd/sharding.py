@@ -62,8 +62,8 @@ def job_throughput(units_local: float, seconds_local: float, device=None, group=
 
 
 def flat_allreduce_mean_(tensors: Sequence[torch.Tensor], group=None) -> None:
-    """In-place mean over ranks of a list of tensors through ONE flat bucket (the gradient exchange of
-    data-parallel training; the backward kernels that would feed it are the next scope row)."""
+    """In-place mean over ranks of a list of tensors through ONE flat bucket: the gradient exchange of
+    data-parallel training, after matgcn_backward has filled the ranks' gradients."""
     tensors = [t for t in tensors if t is not None]
     if not tensors:
         return
@@ -77,13 +77,16 @@ def flat_allreduce_mean_(tensors: Sequence[torch.Tensor], group=None) -> None:
         off += n
 
 
-def replicas_in_sync(params: Iterable[torch.Tensor], group=None) -> bool:
-    """True when every rank holds bit-identical parameters (checksum all-reduce MIN/MAX)."""
+def replicas_in_sync(params: Iterable[torch.Tensor], group=None, device=None) -> bool:
+    """True when every rank holds bit-identical parameters (checksum all-reduce MIN/MAX).  ``device``: where the
+    two checksums travel (a GPU for the nccl/RCCL backend, None = CPU for gloo)."""
     acc = torch.zeros(2, dtype=torch.float64)
     for p in params:
         v = p.detach().double().cpu()
         acc[0] += v.sum()
         acc[1] += (v * v).sum()
+    if device is not None:
+        acc = acc.to(device)
     lo, hi = acc.clone(), acc.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
