@@ -287,11 +287,19 @@ def main():
         if os.path.exists(tpath) and args.workload == "bm403" and w["batch"] == 64:
             with open(tpath) as fh:
                 traffic = json.load(fh)
+        mfma_pmc = None
+        mpath = os.path.join(ROOT, "profiles", "r01_v7_mfma_util.json")
+        if os.path.exists(mpath) and args.workload == "bm403" and w["batch"] == 64:
+            with open(mpath) as fh:
+                mfma_pmc = json.load(fh)["kernels"].get("void k_mix<1>(MixArgs)")
         times = conc
         roofline = dict(bound="mfma", kernel="k_mix<1>", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
                         unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS,
                         traffic=(traffic or {}).get("hbm_bytes_per_launch"),
                         traffic_detail=traffic,
+                        mfma_util_pmc=mfma_pmc and dict(mfma_pmc, source="profiles/r01_v7_mfma_util.json: rocprofv3 --pmc "
+                                                        "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), "
+                                                        "tools/pmc_mfma.sh"),
                         launches=len(step_mix), avg_launch_ms=mix_ms,
                         flops_per_launch=mix_flops,
                         measured="HIP events around each launch, wavefront off (kernel alone on the chip)",
