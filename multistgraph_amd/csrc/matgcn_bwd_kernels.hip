@@ -48,13 +48,25 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   const float* A = g.A + (size_t)b1 * g.bA1 + (size_t)b2 * g.bA2;
   const float* B = g.B + (size_t)b1 * g.bB1 + (size_t)b2 * g.bB2;
   float* C = g.C + (size_t)b1 * g.bC1 + (size_t)b2 * g.bC2;
-  // element of the 64 x 16 A tile (16 x 64 B tile) this thread loads in sweep i: the unit-stride axis runs fastest
+  // element of the 64 x 16 A tile (16 x 64 B tile) this thread loads in sweep i: the unit-stride axis runs fastest.
+  // When pointer and strides are 16-byte friendly the whole tile is ONE float4 per thread along the unit-stride axis
+  // (vecA / vecB, wave-uniform); ragged edges fall back to scalar loads per element of the quad.
   const bool aK = g.sAk == 1, bN = g.sBn == 1;
+  const bool aM = g.sAm == 1, bK = g.sBk == 1;
+  auto aligned4 = [](const float* p, long s0, long s1, long s2) {
+    return ((reinterpret_cast<size_t>(p) & 15) == 0) && (s0 & 3) == 0 && (s1 & 3) == 0 && (s2 & 3) == 0;
+  };
+  const bool vecA = (aK && aligned4(A, g.sAm, g.sAk2, 0)) || (aM && !aK && aligned4(A, g.sAk, g.sAk2, 0));
+  const bool vecB = (bN && aligned4(B, g.sBk, g.sBk2, 0)) || (bK && !bN && aligned4(B, g.sBn, g.sBk2, 0));
   int am[4], ak[4], bk[4], bn[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (aK) { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; } else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
-    if (bN) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
+    if (vecA) {
+      if (aK) { am[i] = tid >> 2; ak[i] = (tid & 3) * 4 + i; } else { ak[i] = tid >> 4; am[i] = (tid & 15) * 4 + i; }
+    } else if (aK) { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; } else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
+    if (vecB) {
+      if (bN) { bk[i] = tid >> 4; bn[i] = (tid & 15) * 4 + i; } else { bn[i] = tid >> 2; bk[i] = (tid & 3) * 4 + i; }
+    } else if (bN) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
   }
   const int kTiles = (g.K + 15) >> 4;
   const long total = (long)g.K2 * kTiles;              // K tiles over (k2, k)
@@ -68,12 +80,30 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   float ra[4], rb[4];
   auto fetch = [&](long tile) {
     const int k2 = (int)(tile / kTiles), k0 = (int)(tile - (long)k2 * kTiles) * 16;
+    const float* Ap = A + (size_t)k2 * g.sAk2;
+    const float* Bp = B + (size_t)k2 * g.sBk2;
+    // the quad of this thread is contiguous in memory along its unit-stride axis: elements 0 and 3 bound it
+    const bool fullA = vecA && m0 + am[3] < g.M && k0 + ak[3] < g.K;
+    if (fullA) {
+      const float4 v = *reinterpret_cast<const float4*>(Ap + (size_t)(m0 + am[0]) * g.sAm + (size_t)(k0 + ak[0]) * g.sAk);
+      ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + am[i], k = k0 + ak[i];
-      ra[i] = (m < g.M && k < g.K) ? A[(size_t)m * g.sAm + (size_t)k2 * g.sAk2 + (size_t)k * g.sAk] : 0.f;
-      const int n = n0 + bn[i], kb = k0 + bk[i];
-      rb[i] = (n < g.N && kb < g.K) ? B[(size_t)kb * g.sBk + (size_t)k2 * g.sBk2 + (size_t)n * g.sBn] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + am[i], k = k0 + ak[i];
+        ra[i] = (m < g.M && k < g.K) ? Ap[(size_t)m * g.sAm + (size_t)k * g.sAk] : 0.f;
+      }
+    }
+    const bool fullB = vecB && n0 + bn[3] < g.N && k0 + bk[3] < g.K;
+    if (fullB) {
+      const float4 v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + bk[0]) * g.sBk + (size_t)(n0 + bn[0]) * g.sBn);
+      rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + bn[i], kb = k0 + bk[i];
+        rb[i] = (n < g.N && kb < g.K) ? Bp[(size_t)kb * g.sBk + (size_t)n * g.sBn] : 0.f;
+      }
     }
   };
   auto stash = [&](int buf) {

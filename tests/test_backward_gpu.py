@@ -64,24 +64,30 @@ def _reference_gemm(a, b, c, desc, alpha, beta):
     dict(M=5, N=130, K=7, K2=6, ta=True, tb=False, nb1=2, nb2=1, mode=0, split=1, beta=1.0),
     dict(M=100, N=20, K=37, K2=9, ta=False, tb=True, nb1=1, nb2=3, mode=1, split=5, beta=0.0),
     dict(M=1, N=1, K=1, K2=1, ta=False, tb=False, nb1=1, nb2=1, mode=1, split=3, beta=0.0),
+    # 16-byte friendly strides: the float4 tile loads, with ragged edges falling back per quad
+    dict(M=128, N=64, K=48, K2=2, ta=False, tb=False, nb1=2, nb2=1, mode=0, split=1, beta=0.0, pad4=True),
+    dict(M=70, N=34, K=45, K2=3, ta=True, tb=True, nb1=1, nb2=2, mode=0, split=1, beta=1.0, pad4=True),
+    dict(M=66, N=130, K=18, K2=1, ta=True, tb=False, nb1=1, nb2=1, mode=1, split=2, beta=0.0, pad4=True),
+    dict(M=64, N=64, K=64, K2=1, ta=False, tb=True, nb1=3, nb2=1, mode=0, split=1, beta=0.0, pad4=True),
 ])
 def test_strided_batched_gemm(case, lib_built):
     from multistgraph_amd.ops import debug_gemm
     rng = np.random.default_rng(7)
     M, N, K, K2, nb1, nb2 = (case[k] for k in ("M", "N", "K", "K2", "nb1", "nb2"))
     # A element (m, k2, k) and B element (k2, k, n) inside padded per-batch blocks; ta/tb swap the fast axis
+    r4 = (lambda v: (v + 3) // 4 * 4) if case.get("pad4") else (lambda v: v)
     if case["ta"]:
-        sAk, sAm = M + 3, 1
+        sAk, sAm = r4(M + 3), 1
     else:
-        sAm, sAk = K + 2, 1
-    sAk2 = (M + 3) * (K + 2)
-    blockA = sAk2 * K2 + 5
+        sAm, sAk = r4(K + 2), 1
+    sAk2 = r4((K * sAk if case["ta"] else M * sAm) + 8)
+    blockA = r4(sAk2 * K2 + 5)
     if case["tb"]:
-        sBn, sBk = K + 1, 1
+        sBn, sBk = r4(K + 1), 1
     else:
-        sBk, sBn = N + 4, 1
-    sBk2 = (K + 1) * (N + 4)
-    blockB = sBk2 * K2 + 3
+        sBk, sBn = r4(N + 4), 1
+    sBk2 = r4((N * sBn if case["tb"] else K * sBk) + 8)
+    blockB = r4(sBk2 * K2 + 3)
     sCm, sCn = N + 2, 1
     blockC = M * sCm + 1
     bA2, bA1 = blockA, blockA * nb2
