@@ -8,7 +8,7 @@ device pointers and the current HIP stream cross the boundary.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import torch

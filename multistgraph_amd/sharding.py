@@ -11,7 +11,7 @@ Nothing here touches the device path; it is plain host logic and is covered by w
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence, Tuple
+from typing import Iterable, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

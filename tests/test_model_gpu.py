@@ -1,5 +1,4 @@
 """The drop-in MultiATGCN class end to end on the GPU: predict, calculate_loss, MAE@k."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,6 @@
 """Training steps of the bench workload (default Baltimore 403, B=64): forward_train + backward through the plugin
 surface (calculate_loss().backward()), timed with HIP events.  usage: train_step.py [workload] [steps]"""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
