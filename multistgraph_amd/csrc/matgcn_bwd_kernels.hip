@@ -69,17 +69,19 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
     } else if (bN) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
   }
   const int kTiles = (g.K + 15) >> 4;
-  const long total = (long)g.K2 * kTiles;              // K tiles over (k2, k)
-  const long per = (total + g.split - 1) / g.split;
-  const long tBeg = (long)part * per, tEnd = tBeg + per < total ? tBeg + per : total;
+  const int total = g.K2 * kTiles;                     // K tiles over (k2, k): far below 2^31 (checked by the launcher)
+  const int per = (total + g.split - 1) / g.split;
+  const int tBeg = part * per, tEnd = tBeg + per < total ? tBeg + per : total;
   f32x4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float ra[4], rb[4];
-  auto fetch = [&](long tile) {
-    const int k2 = (int)(tile / kTiles), k0 = (int)(tile - (long)k2 * kTiles) * 16;
+  int fk2 = tBeg / kTiles, fkt = tBeg - fk2 * kTiles;   // (k2, k tile) of the next fetch: advanced, never divided again
+  auto fetch = [&]() {
+    const int k2 = fk2, k0 = fkt * 16;
+    if (++fkt == kTiles) { fkt = 0; ++fk2; }
     const float* Ap = A + (size_t)k2 * g.sAk2;
     const float* Bp = B + (size_t)k2 * g.sBk2;
     // the quad of this thread is contiguous in memory along its unit-stride axis: elements 0 and 3 bound it
@@ -114,13 +116,13 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
     }
   };
   if (tBeg < tEnd) {
-    fetch(tBeg);
+    fetch();
     stash(0);
     __syncthreads();
     int buf = 0;
-    for (long tile = tBeg; tile < tEnd; ++tile) {
+    for (int tile = tBeg; tile < tEnd; ++tile) {
       const bool more = tile + 1 < tEnd;
-      if (more) fetch(tile + 1);
+      if (more) fetch();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = 4 * s + kq;
