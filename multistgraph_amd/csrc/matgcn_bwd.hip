@@ -34,7 +34,7 @@ void launch_bgemm(const dim3& grid, hipStream_t s, const GemmArgs& g) {
 int gemm(const GemmArgs& g, int nb1, hipStream_t s, int role = BG_GENERIC) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K2 <= 0 || nb1 <= 0) return MATGCN_OK;
   const long gx = (g.N + 63) / 64, gy = (g.M + 63) / 64, gz = (long)nb1 * g.nb2 * g.split;
-  if (gy > 65535 || gz > 65535 || (long)g.K2 * ((g.K + 15) / 16) >= (1L << 30)) return MATGCN_ERR_UNSUPPORTED;
+  if (gy > 65535 || gz > 65535 || (long)g.K2 * ((g.K + BG_KT - 1) / BG_KT) >= (1L << 30)) return MATGCN_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
   switch (role) {
     case BG_CHAIN_DENSE: launch_bgemm<BG_CHAIN_DENSE>(grid, s, g); break;

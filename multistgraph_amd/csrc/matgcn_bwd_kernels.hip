@@ -30,14 +30,18 @@ struct GemmArgs {
 };
 
 #define BG_LD 80   // LDS row pitch (floats): lanes with kq = 0..3 land 16 banks apart
+#ifndef BG_KH
+#define BG_KH 1    // 16-wide K halves per staged tile (2 was measured: no gain at the backward's shapes, twice the LDS)
+#endif
+#define BG_KT (16 * BG_KH)
 
 // ROLE only names the instantiation, so that profilers list the call sites of the backward on separate lines
 enum { BG_GENERIC = 0, BG_CHAIN_DENSE, BG_CHAIN_NODE, BG_CHAIN_MIX, BG_X_NODE, BG_X_MIX, BG_WGRAD, BG_ADJ, BG_LINEAR,
        BG_POOL, BG_HEAD, BG_ROLES };
 template <int ROLE>
 __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
-  __shared__ float As[2][16][BG_LD];
-  __shared__ float Bs[2][16][BG_LD];
+  __shared__ float As[2][BG_KT][BG_LD];
+  __shared__ float Bs[2][BG_KT][BG_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
       if (bN) { bk[i] = tid >> 4; bn[i] = (tid & 15) * 4 + i; } else { bn[i] = tid >> 2; bk[i] = (tid & 3) * 4 + i; }
     } else if (bN) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
   }
-  const int kTiles = (g.K + 15) >> 4;
+  const int kTiles = (g.K + BG_KT - 1) / BG_KT;
   const int total = g.K2 * kTiles;                     // K tiles over (k2, k): far below 2^31 (checked by the launcher)
   const int per = (total + g.split - 1) / g.split;
   const int tBeg = part * per, tEnd = tBeg + per < total ? tBeg + per : total;
@@ -77,43 +81,49 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ra[4], rb[4];
+  float ra[BG_KH][4], rb[BG_KH][4];
   int fk2 = tBeg / kTiles, fkt = tBeg - fk2 * kTiles;   // (k2, k tile) of the next fetch: advanced, never divided again
   auto fetch = [&]() {
-    const int k2 = fk2, k0 = fkt * 16;
+    const int k2 = fk2, kBase = fkt * BG_KT;
     if (++fkt == kTiles) { fkt = 0; ++fk2; }
     const float* Ap = A + (size_t)k2 * g.sAk2;
     const float* Bp = B + (size_t)k2 * g.sBk2;
-    // the quad of this thread is contiguous in memory along its unit-stride axis: elements 0 and 3 bound it
-    const bool fullA = vecA && m0 + am[3] < g.M && k0 + ak[3] < g.K;
-    if (fullA) {
-      const float4 v = *reinterpret_cast<const float4*>(Ap + (size_t)(m0 + am[0]) * g.sAm + (size_t)(k0 + ak[0]) * g.sAk);
-      ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
-    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + am[i], k = k0 + ak[i];
-        ra[i] = (m < g.M && k < g.K) ? Ap[(size_t)m * g.sAm + (size_t)k * g.sAk] : 0.f;
+    for (int h = 0; h < BG_KH; ++h) {
+      const int k0 = kBase + 16 * h;
+      // the quad of this thread is contiguous in memory along its unit-stride axis: elements 0 and 3 bound it
+      const bool fullA = vecA && m0 + am[3] < g.M && k0 + ak[3] < g.K;
+      if (fullA) {
+        const float4 v = *reinterpret_cast<const float4*>(Ap + (size_t)(m0 + am[0]) * g.sAm + (size_t)(k0 + ak[0]) * g.sAk);
+        ra[h][0] = v.x; ra[h][1] = v.y; ra[h][2] = v.z; ra[h][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + am[i], k = k0 + ak[i];
+          ra[h][i] = (m < g.M && k < g.K) ? Ap[(size_t)m * g.sAm + (size_t)k * g.sAk] : 0.f;
+        }
       }
-    }
-    const bool fullB = vecB && n0 + bn[3] < g.N && k0 + bk[3] < g.K;
-    if (fullB) {
-      const float4 v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + bk[0]) * g.sBk + (size_t)(n0 + bn[0]) * g.sBn);
-      rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
-    } else {
+      const bool fullB = vecB && n0 + bn[3] < g.N && k0 + bk[3] < g.K;
+      if (fullB) {
+        const float4 v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + bk[0]) * g.sBk + (size_t)(n0 + bn[0]) * g.sBn);
+        rb[h][0] = v.x; rb[h][1] = v.y; rb[h][2] = v.z; rb[h][3] = v.w;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = n0 + bn[i], kb = k0 + bk[i];
-        rb[i] = (n < g.N && kb < g.K) ? Bp[(size_t)kb * g.sBk + (size_t)n * g.sBn] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const int n = n0 + bn[i], kb = k0 + bk[i];
+          rb[h][i] = (n < g.N && kb < g.K) ? Bp[(size_t)kb * g.sBk + (size_t)n * g.sBn] : 0.f;
+        }
       }
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      As[buf][ak[i]][am[i]] = ra[i];
-      Bs[buf][bk[i]][bn[i]] = rb[i];
-    }
+    for (int h = 0; h < BG_KH; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        As[buf][16 * h + ak[i]][am[i]] = ra[h][i];
+        Bs[buf][16 * h + bk[i]][bn[i]] = rb[h][i];
+      }
   };
   if (tBeg < tEnd) {
     fetch();
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
       const bool more = tile + 1 < tEnd;
       if (more) fetch();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 4 * BG_KH; ++s) {
         const int k = 4 * s + kq;
         float av[2], bv[2];
 #pragma unroll
