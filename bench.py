@@ -100,6 +100,32 @@ def cpu_baseline(w, seed, x_np, model_state, df, pred_gpu):
                 seconds=dt, gpu_vs_cpu_max_norm_err=err), pred
 
 
+def cpu_train_baseline(w, x_np, y_np, model_state, df, sample=8):
+    """The training step on the host cores - calculate_loss(batch).backward() by torch autograd through the oracle
+    (fp32) - on a bounded sample of the workload (`sample` of the batch's rows).  The oracle runs with the
+    parameter-only work hoisted out of the time loop (faithful=False): the reference rebuilds the node-adaptive
+    weights in all 96 AGCN calls, a batch-independent cost that would dominate a small sample, so this is an UPPER
+    bound of the reference's CPU rate per node-step."""
+    from oracle import matgcn_oracle as O
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model_state.items()}
+    st = O.supports_as_tensors(O.static_supports(df["adj_mx"], df["coordinate"], None, "multi"))
+    cfg = dict(adjtype="multi", adpadj="unidirection", cheb_order=2, num_layers=2, rnn_units=64,
+               len_closeness=48, len_period=24, len_trend=24, output_window=w["out"], input_window=24,
+               add_time_in_day=True, add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=1)
+    xb, yb = torch.from_numpy(x_np[:sample]), torch.from_numpy(y_np[:sample])
+    t0 = time.perf_counter()
+    loss = O.calculate_loss(xb, yb, p, st, cfg, faithful=False)
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    units = xb.shape[0] * 24 * w["nodes"]
+    return dict(value=units / (t2 - t0), unit="node-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 training step (calculate_loss + backward, torch autograd through the oracle with hoisted "
+                       "weights: an upper bound of the reference's rate) on %d of the batch's %d rows: forward %.2f s + backward %.2f s on %d torch threads" % (
+                           xb.shape[0], x_np.shape[0], t1 - t0, t2 - t1, torch.get_num_threads()),
+                seconds=t2 - t0)
+
+
 def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     """Instrumented forwards: HIP events around every kernel launch of the path, on its stream."""
     from multistgraph_amd import _lib
@@ -346,7 +372,18 @@ def main():
                                                        torch.from_numpy(y_np)[:, min(12, w["out"]) - 1, :, 0:1]).item())
             result["gpu_over_cpu"] = value / base["value"]
         if world == 1 and not args.no_train_step:
-            result["train_step"] = train_step_times(model, batch, w)
+            cpu_train = None
+            if not args.no_cpu_baseline and args.workload != "synth4096":
+                cpu_train = cpu_train_baseline(w, x_np, y_np, dict(model.named_parameters()), df)   # before the weights move
+            ts = train_step_times(model, batch, w)
+            # every forward GEMM has two backward GEMMs (input gradient, weight gradient): backward ~ 2x forward FLOPs
+            bwd_flops = 2.0 * flops_unit * w["batch"] * 24 * w["nodes"]
+            ts["backward_algorithmic_tflops"] = bwd_flops / (ts["backward_ms"] * 1e-3) / 1e12
+            ts["backward_frac_mfma"] = ts["backward_algorithmic_tflops"] / PEAK_MFMA_F32_TFLOPS
+            if cpu_train is not None:
+                ts["cpu_baseline"] = cpu_train
+                ts["gpu_over_cpu"] = ts["node_steps_per_s"] / cpu_train["value"]
+            result["train_step"] = ts
     if distributed and not args.no_train_step:
         # every rank takes part (the gradient all-reduce is a collective); rank 0 reports
         try:
