@@ -216,7 +216,13 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(zero_async(tr + R.oDWp[l][part], (long)N * S * I * O, s));
       RETURN_IF(zero_async(tr + R.oDBias[l][part], (long)N * O, s));
     }
-  RETURN_IF(zero_async(tr + R.oDSeq[0], (long)T * slab, s));
+  if (hT < T) {
+    RETURN_IF(zero_async(tr + R.oDSeq[0], (long)T * slab, s));
+  } else if (Np != N) {   // the head GEMM writes every step of every real node: only the padding rows need clearing
+    hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * (Np - N) * H)), dim3(256), 0, s, tr + R.oDSeq[0],
+                       rowsTB, N, Np, H);
+    CHECK_LAUNCH();
+  }
   RETURN_IF(zero_async(tr + R.oMixOut, slab, s));
   RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
   if (Np != N)
@@ -688,7 +694,14 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   RETURN_IF(make_train_plan(P, &c.R));
   if (train_bytes < (size_t)c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   c.train = (float*)train;
-  RETURN_IF(zero_async(c.train, c.R.savedFloats, c.s));   // rows of the padding nodes stay zero
+  // the forward kernels write the rows of the real nodes only: the rows of the padding nodes must read as zero.  The
+  // saved tensors are contiguous [T][B][Np][64] blocks, so one launch clears the padding rows of all of them.
+  if (P.Np != P.N) {
+    const size_t rows = (size_t)(c.R.savedFloats / ((long)P.Np * H));
+    hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for(rows * (P.Np - P.N) * H)), dim3(256), 0, c.s, c.train,
+                       (int)rows, P.N, P.Np, H);
+    CHECK_LAUNCH();
+  }
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
