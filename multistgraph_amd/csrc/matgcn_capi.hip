@@ -135,7 +135,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oR[l] = take((long)P->N * P->B * H);
     P->oSeq[l] = take(rowsBT * P->Np * H);
     if (l > 0 && !P->gcnOff) {
-      P->oGX[l] = take((long)P->N * P->B * P->Tc * P->Ks * H);
+      P->oGX[l] = take((long)P->T * P->N * P->B * P->Ks * H);   // every chunk keeps its own block [N][nt*B][Ks][64]
       P->oPX[l] = take((long)P->T * P->N * P->B * 192);
     }
   }
@@ -276,6 +276,7 @@ struct Wavefront {
   hipEvent_t fork, done[MATGCN_MAX_LAYERS];
   hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
+  hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
 };
 Wavefront g_wf;
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
@@ -292,6 +293,7 @@ int wavefront_ready() {
     for (int t = 0; t < MAX_STEPS; ++t) {
       HIP_OK(hipEventCreateWithFlags(&g_wf.step[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.xdone[l][t], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_wf.mixed[l][t], hipEventDisableTiming));
     }
   }
 
@@ -316,9 +318,12 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
 }
 
 // mix of `rows` contiguous [Np][64] slabs into the node-major buffer G [N][rows][Ks][64]
-int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s, bool stepRole = false) {
-  return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, (long)rows * P.Ks * H, H, (long)P.Ks * H, P.Ks,
-                    P.Ks * P.Np, s, stepRole, (long)P.N * rows * P.Ks * H);
+// (nodeStride: floats between the nodes of G when the `rows` rows are a slice of a larger node-major block)
+int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G, hipStream_t s, bool stepRole = false,
+             long nodeStride = 0) {
+  const long sN = nodeStride ? nodeStride : (long)rows * P.Ks * H;
+  return launch_mix(P, St, X, (long)P.Np * H, H, rows, G, sN, H, (long)P.Ks * H, P.Ks, P.Ks * P.Np, s, stepRole,
+                    (long)(P.N - 1) * sN + (long)rows * P.Ks * H);
 }
 
 struct Ctx {
@@ -377,12 +382,18 @@ inline int chunk_steps(const Plan& P, int t) {
 
 // layers >= 1: hoisted x part of steps [t0, t0+nt) -> PX_l[t0..].  xin: time-major rows [nt*B][Np][64] of the
 // layer below (MultiATGCN.py:106-108 restricted to the x rows, + bias)
-int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s) {
+// mixedSteps: how many of the chunk's first steps already have their mixed rows in place - written there by the layer
+// below, whose recurrent mix of h_t IS the mix of this layer's input x_t (see shared_mix_slot)
+int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s, int mixedSteps = 0) {
   const Plan& P = c.P;
   const int rows = P.B * nt;
   // training keeps the mixed rows of every chunk for the weight gradients
-  float* GX = c.train ? c.train + c.R.oGX[l] + (size_t)t0 * P.N * P.B * P.Ks * H : c.ws + P.oGX[l];
-  RETURN_IF(mix_rows(P, c.prep + P.oSt, xin, rows, GX, s));
+  float* GX = (c.train ? c.train + c.R.oGX[l] : c.ws + P.oGX[l]) + (size_t)t0 * P.N * P.B * P.Ks * H;
+  if (mixedSteps < nt) {
+    const int r0 = mixedSteps * P.B;
+    RETURN_IF(mix_rows(P, c.prep + P.oSt, xin + (size_t)mixedSteps * P.B * P.Np * H, rows - r0,
+                       GX + (size_t)r0 * P.Ks * H, s, false, mixedSteps ? (long)rows * P.Ks * H : 0));
+  }
   Px16Args a;
   a.x = xin; a.g = GX; a.w = c.prep + P.oWx[l]; a.bias = c.prep + P.oBx[l];
   a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.B * 192;
@@ -390,6 +401,21 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
   ProfScope prof(MATGCN_PROF_PX, s);
   hipLaunchKernelGGL(k_px16, dim3((unsigned)(rup(P.N, 8) * ((rows + 63) / 64))), dim3(512), P.nodeLds, s, a);
   return launch_ok();
+}
+
+// The recurrent mix of layer l at step t+1 (phase 0: mix of h_t) equals the x-part mix of layer l+1 at step t, so in
+// inference layer l writes it straight into layer l+1's chunk block and reads it from there: slot of step t inside
+// the block of the chunk that holds it.  Returns false when the mix stays private (last layer, training, gcn_off).
+bool shared_mix_slot(const Ctx& c, int l, int t, float** g, long* nodeStride) {
+  const Plan& P = c.P;
+  if (c.train || P.gcnOff || l + 1 >= P.L || t < 0 || t >= P.T || P.Ks <= 0) return false;
+  int t0 = 0;
+  while (t0 + chunk_steps(P, t0) <= t) t0 += chunk_steps(P, t0);
+  const int nt = chunk_steps(P, t0);
+  const size_t gStep = (size_t)P.N * P.B * P.Ks * H;
+  *g = c.ws + P.oGX[l + 1] + t0 * gStep + (size_t)(t - t0) * P.B * P.Ks * H;
+  *nodeStride = (long)nt * P.B * P.Ks * H;
+  return true;
 }
 
 // residual-cell operands of layer l at step t for the fused update kernel
@@ -409,14 +435,17 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   float* Hx = c.ws + P.oHx[l];
   float* ZHx = c.ws + P.oZHx[l];
   float* G = c.ws + P.oG[l];
+  long gNodeStride = 0;
   if (c.train && res)   // training keeps the mixed rows of every step (weight gradients of the backward)
     G = c.train + (phase < 2 ? c.R.oGH[l] : c.R.oGZH[l]) + (size_t)t * P.N * P.B * P.Ks * H;
+  else if (res && phase < 2)   // the mix of h_{t-1} doubles as the next layer's x-part mix of step t-1
+    (void)shared_mix_slot(c, l, t - 1, &G, &gNodeStride);
   float* R = c.ws + P.oR[l];
-  if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true);
+  if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true, gNodeStride);
   if (phase == 2) return mix_rows(P, St, ZHx, P.B, G, s, true);
   Node16Args a;
   memset(&a, 0, sizeof(a));
-  a.g = G; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
+  a.g = G; a.gNodeStride = phase == 1 ? gNodeStride : 0; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
   else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.B * 192;
   const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
@@ -537,8 +566,16 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
         // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
         const int nt = chunk_steps(P, t);
         nextChunk = t + nt;
-        if (multi) HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
-        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs));
+        // steps whose mixed rows the layer below has already written into this chunk's block (its recurrent mix of
+        // h_t at its step t+1): all but the sequence's last step
+        float* slot; long stride;
+        int mixedSteps = 0;
+        if (shared_mix_slot(c, l - 1, t, &slot, &stride)) mixedSteps = P.T - 1 - t < nt ? P.T - 1 - t : nt;
+        if (multi) {
+          if (mixedSteps == nt) HIP_OK(hipStreamWaitEvent(xs, W.mixed[l - 1][t + nt], 0));
+          else HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
+        }
+        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs, mixedSteps));
         if (multi) {
           HIP_OK(hipEventRecord(W.xdone[l][t], xs));
           HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
@@ -551,7 +588,11 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
       else
         fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, c.prm->weights_gru + (size_t)l * P.T + t,
                       seq + t * stepRows, &res);
-      RETURN_IF(cell_step(c, l, t, nullptr, false, &res, cs));
+      RETURN_IF(cell_phase(c, l, t, 0, nullptr, &res, cs));
+      if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.mixed[l][t], cs));
+      RETURN_IF(cell_phase(c, l, t, 1, nullptr, &res, cs));
+      RETURN_IF(cell_phase(c, l, t, 2, nullptr, &res, cs));
+      RETURN_IF(cell_phase(c, l, t, 3, nullptr, &res, cs));
       if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
     }
     if (finalsUser) {

@@ -31,6 +31,7 @@
 struct Node16Args {
   const float* s;        // [rows][Np][64]: h (gate / res-only) or z*h (update)
   const float* g;        // [N][rows][Ks][64] graph-mixed s
+  long gNodeStride;      // floats between the nodes of g; 0 = rows*Ks*64 (the block may sit inside a larger one)
   const float* w;        // [N][nG][OT][64][4] recurrent rows of the node-adaptive weights (fragment order)
   const float* px;       // [N][rows][192] hoisted pre-activation of this step (x rows + bias): gate 0:128, update
                          // 128:192 - layers >= 1; null for layer 0, whose narrow x part is contracted in the kernel:
@@ -97,7 +98,8 @@ __device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int 
   float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)gA * a.Np + n) * 64 + q * 4);
   float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)gB * a.Np + n) * 64 + q * 4);
   const int spr = 16 * a.Ks;
-  const float4* gsrc = reinterpret_cast<const float4*>(a.g + (size_t)n * a.rows * spr * 4);
+  const float4* gsrc = reinterpret_cast<const float4*>(
+      a.g + (size_t)n * (a.gNodeStride ? (size_t)a.gNodeStride : (size_t)a.rows * spr * 4));
   const int pA = q ^ (rA & 15), pB = q ^ (rB & 15);
   if (a.Ks == 0) {   // no dense support left (all folded): only the s slots
     *reinterpret_cast<float4*>(&Hs[(rA * 16 + pA) * 4]) = keep4(vA, hA);
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   const float4* wp0 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
   const float4* wp1 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + min(w + 8, 11)) * 64 + lane;
   Node16Args a;                                 // staging helper speaks Node16Args
-  a.s = p.x; a.g = p.g; a.rows = p.rows; a.Np = p.Np; a.Ks = p.Ks;
+  a.s = p.x; a.g = p.g; a.gNodeStride = 0; a.rows = p.rows; a.Np = p.Np; a.Ks = p.Ks;
   stage_node_tile(a, n, rowBase, Hs, Gs);
   float4 wr0[PX16_RING], wr1[PX16_RING];
 #pragma unroll
