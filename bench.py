@@ -62,6 +62,18 @@ def algorithmic_flops_per_unit(n, k_total=5, c0=2, h=64, out=24):
     return total + 2 * h * out
 
 
+def executed_flops_per_unit(n, ks, c0=2, h=64, out=24, steps=24):
+    """What the kernels really multiply, per node-step: `ks` dense supports only (diagonal ones are folded into the
+    weights); the x columns are mixed once per layer, not once per AGCN; and for layers >= 1 that mix is the recurrent
+    mix of the layer below (shared), except for the sequence's last step."""
+    total = 0.0
+    for l, c_l in enumerate((c0, h)):
+        i_l = c_l + h
+        x_mix = 2 * ks * n * c_l * (1.0 if l == 0 else 1.0 / steps)
+        total += 4 * ks * n * h + x_mix + 6 * (ks + 1) * i_l * h + 6 * i_l * h
+    return total + 2 * h * out
+
+
 def algorithmic_bytes_per_unit(c0=2, h=64, elem=4):
     return elem * ((2 * c0 + 7 * h) + (2 * h + 7 * h))
 
@@ -335,10 +347,12 @@ def main():
                         dense_supports_mixed=ks, supports_folded_into_weights=n_diag * (spec.cheb_k - 1),
                         whole_forward=dict(algorithmic_tflops=fwd_tflops,
                                            frac_mfma=fwd_tflops / PEAK_MFMA_F32_TFLOPS,
-                                           executed_tflops=fwd_tflops * algorithmic_flops_per_unit(
-                                               w["nodes"], k_total=1 + ks, out=w["out"]) / flops_unit,
-                                           note="algorithmic = SURVEY section 8d formula (all K-1 supports dense); "
-                                                "executed = same formula with the folded diagonal supports removed",
+                                           executed_tflops=fwd_tflops * executed_flops_per_unit(
+                                               w["nodes"], ks, out=w["out"]) / flops_unit,
+                                           note="algorithmic = SURVEY section 8d formula (all K-1 supports dense, x columns "
+                                                "mixed in both AGCNs of every layer); executed = what the kernels multiply: "
+                                                "dense supports only, x columns mixed once per layer and, for layers >= 1, "
+                                                "shared with the recurrent mix of the layer below",
                                            algorithmic_gbs=algorithmic_bytes_per_unit() * units_per_step / world /
                                            (ms_per_step * 1e-3) / 1e9,
                                            flops_per_unit=flops_unit),
