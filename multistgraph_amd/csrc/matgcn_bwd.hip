@@ -136,12 +136,13 @@ struct MixedRows {
 
 // dWp[n][s][iOfs + i][o] += sum_rows [U | mix(U)][rows][n][s][i] * dPre[rows][n][o] over `rows` consecutive (t, b) rows
 // starting at row0; U rows are [Np][Cc] slabs, the mixed rows come as the forward stored them
+// (parts: 1 = identity slot only, 2 = dense slots only, 3 = both)
 int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, const float* dPre, int O, int I, int iOfs,
-                     long row0, int rows, float* dWp) {
+                     long row0, int rows, float* dWp, int parts = 3) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
   const float* dP = dPre + (size_t)row0 * P.Np * O;
-  {  // identity slot: the rows themselves
+  if (parts & 1) {  // identity slot: the rows themselves
     GemmArgs g = gemm_args(U + (size_t)row0 * P.Np * Cc, dP, dWp + (size_t)iOfs * O, Cc, O, rows);
     g.sAm = 1; g.sAk = (long)P.Np * Cc; g.bA1 = Cc;
     g.sBk = (long)P.Np * O; g.sBn = 1; g.bB1 = O;
@@ -149,7 +150,7 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
     g.beta = 1.f;
     RETURN_IF(gemm(g, P.N, b.c.s, BG_WGRAD));
   }
-  if (P.Ks > 0) {  // dense slots: the mixed rows
+  if ((parts & 2) && P.Ks > 0 && mr.K > 0) {  // dense slots: the mixed rows
     GemmArgs g = gemm_args(mr.G, dP, dWp + (size_t)I * O + (size_t)iOfs * O, Cc, O, mr.K);
     g.K2 = mr.K2;
     g.sAm = 1; g.sAk = mr.sK; g.sAk2 = mr.sK2; g.bA1 = mr.sNode; g.bA2 = mr.sSlot;
@@ -498,9 +499,24 @@ int backward_impl(Bwd& b, const float* dOut) {
     float* dWpG = tr + R.oDWp[l][0];
     float* dWpU = tr + R.oDWp[l][1];
     const long gStep = (long)N * B * P.Ks * H;
-    {  // recurrent rows: [T][N][B][Ks][64]
+    if (l + 1 < P.L && P.Ks > 0) {
+      // the mix of h_{t-1} was written into the chunk blocks of the layer above (its x-part mix of step t-1, see
+      // shared_mix_slot): identity slot over all rows, dense slots chunk by chunk, shifted by one step; the mix of
+      // the zero state at t = 0 contributes nothing
+      MixedRows none = {nullptr, 0, 0, 0, 0, 0, 0};
+      RETURN_IF(node_weight_grad(bw, Hprev, none, H, DPG, 128, I, C, 0, rowsTB, dWpG, 1));
+      for (int t0 = 0; t0 < T;) {
+        const int nt = chunk_steps(P, t0);
+        const int ntm = T - 1 - t0 < nt ? T - 1 - t0 : nt;   // the block's last slot of the sequence feeds nobody here
+        MixedRows mh = {tr + R.oGX[l + 1] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, ntm * B};
+        RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, (long)(t0 + 1) * B, ntm * B, dWpG, 2));
+        t0 += nt;
+      }
+    } else {  // recurrent rows of the top layer: private blocks [T][N][B][Ks][64]
       MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
       RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
+    }
+    {
       MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
       RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
     }

@@ -151,7 +151,8 @@ struct TrainPlan {
   long oZ2[MATGCN_MAX_LAYERS], oR2[MATGCN_MAX_LAYERS], oHC2[MATGCN_MAX_LAYERS];
   long oSeqDrop;                           // the top sequence after dropout (what the head saw), [T][B][Np][64]
   long savedFloats;                        // [0, savedFloats) is zeroed by forward_train
-  // graph-mixed rows of every step as the forward wrote them, [T][N][B][Ks][64] (x part: per chunk [N][nt*B][Ks][64]);
+  // graph-mixed rows of every step as the forward wrote them, [T][N][B][Ks][64] (x part: per chunk [N][nt*B][Ks][64],
+  // which also holds the recurrent mix of the layer below; oGH exists for the top layer only);
   // written in full by forward_train, never zeroed
   long oGH[MATGCN_MAX_LAYERS], oGZH[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS];
   long keepFloats;                         // [keepFloats, floats) is zeroed by backward
@@ -183,7 +184,10 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->savedFloats = o;
   const long gAll = (long)P.T * P.N * P.B * P.Ks * H;
   for (int l = 0; l < P.L; ++l) {
-    R->oGH[l] = take(gAll); R->oGZH[l] = take(gAll);
+    // the recurrent mix of a layer below the top one lives in the chunk blocks of the layer above (shared_mix_slot)
+    const bool sharedUp = l + 1 < P.L && !P.gcnOff && P.Ks > 0;
+    R->oGH[l] = sharedUp ? 0 : take(gAll);
+    R->oGZH[l] = take(gAll);
     if (l > 0) R->oGX[l] = take(gAll);
   }
   R->keepFloats = o;
@@ -404,16 +408,17 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
 }
 
 // The recurrent mix of layer l at step t+1 (phase 0: mix of h_t) equals the x-part mix of layer l+1 at step t, so in
-// inference layer l writes it straight into layer l+1's chunk block and reads it from there: slot of step t inside
-// the block of the chunk that holds it.  Returns false when the mix stays private (last layer, training, gcn_off).
+// layer l writes it straight into layer l+1's chunk block and reads it from there: slot of step t inside the block of
+// the chunk that holds it (in the workspace, or in the training buffer, which keeps every block for the backward).
+// Returns false when the mix stays private (last layer, gcn_off, nothing to mix).
 bool shared_mix_slot(const Ctx& c, int l, int t, float** g, long* nodeStride) {
   const Plan& P = c.P;
-  if (c.train || P.gcnOff || l + 1 >= P.L || t < 0 || t >= P.T || P.Ks <= 0) return false;
+  if (P.gcnOff || l + 1 >= P.L || t < 0 || t >= P.T || P.Ks <= 0) return false;
   int t0 = 0;
   while (t0 + chunk_steps(P, t0) <= t) t0 += chunk_steps(P, t0);
   const int nt = chunk_steps(P, t0);
   const size_t gStep = (size_t)P.N * P.B * P.Ks * H;
-  *g = c.ws + P.oGX[l + 1] + t0 * gStep + (size_t)(t - t0) * P.B * P.Ks * H;
+  *g = (c.train ? c.train + c.R.oGX[l + 1] : c.ws + P.oGX[l + 1]) + t0 * gStep + (size_t)(t - t0) * P.B * P.Ks * H;
   *nodeStride = (long)nt * P.B * P.Ks * H;
   return true;
 }
@@ -436,10 +441,11 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   float* ZHx = c.ws + P.oZHx[l];
   float* G = c.ws + P.oG[l];
   long gNodeStride = 0;
-  if (c.train && res)   // training keeps the mixed rows of every step (weight gradients of the backward)
+  // the mix of h_{t-1} doubles as the next layer's x-part mix of step t-1; otherwise training keeps the mixed rows of
+  // every step in private per-step blocks (weight gradients of the backward)
+  const bool shared = res && phase < 2 && shared_mix_slot(c, l, t - 1, &G, &gNodeStride);
+  if (!shared && c.train && res)
     G = c.train + (phase < 2 ? c.R.oGH[l] : c.R.oGZH[l]) + (size_t)t * P.N * P.B * P.Ks * H;
-  else if (res && phase < 2)   // the mix of h_{t-1} doubles as the next layer's x-part mix of step t-1
-    (void)shared_mix_slot(c, l, t - 1, &G, &gNodeStride);
   float* R = c.ws + P.oR[l];
   if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true, gNodeStride);
   if (phase == 2) return mix_rows(P, St, ZHx, P.B, G, s, true);
