@@ -329,6 +329,9 @@ int backward_impl(Bwd& b, const float* dOut) {
     const float* WpU = tr + R.oWp[l][1];
     const float* RG = prm->res_gate[l].weight;     // (128, I)
     const float* RU = prm->res_update[l].weight;   // (64, I)
+    // x_t of layer l+1 IS h_t of layer l: the gradient of [x | mix(x)] of the layer above (steps 0..T-2) was written
+    // into this layer's gate block of step t+1 and is back-propagated together with it
+    const bool mergeAbove = !P.gcnOff && l + 1 < P.L;
     if (P.gcnOff) {
       // ablation: the layer is one dense GRU cell per step on (x_t, h) (MultiATGCN.py:142-150,187-192,204); its
       // nn.Linear parameters travel in the res_* fields.  z, r, hc were saved in the residual-cell slots.
@@ -429,7 +432,9 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
       hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
       CHECK_LAUNCH();
-      RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, 0.f));
+      // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
+      // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
+      RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
       RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
     }
     // ---------------- everything that batches over the T steps ----------------
@@ -452,13 +457,37 @@ int backward_impl(Bwd& b, const float* dOut) {
       hipLaunchKernelGGL(k_narrow_gather, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s,
                          P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
       CHECK_LAUNCH();
-    } else {
+    } else if (l == 0) {   // a 64-channel input layer: nothing below to ride with
       RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
       RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
       RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
       RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
       hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
                          (size_t)rowsTB, Np, C, S);
+      CHECK_LAUNCH();
+    } else {
+      // layers >= 1: steps 0..T-2 go into the gate block of the layer below at step t+1 (see mergeAbove); only the
+      // sequence's last step, which no step of the layer below follows, is mixed back here
+      const int parBelow = (l - 1) & 1;
+      float* DAgBelow = tr + R.oDAg[parBelow];
+      if (twoStreams && l + 1 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 1], 0));   // its readers are done
+      RETURN_IF(zero_async(DAgBelow, slab * S, s));                                         // step 0: nothing from above
+      if (Np != N) {
+        hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)B * S * (Np - N) * H)), dim3(256), 0, s, DAx, B * S, N, Np,
+                           H);
+        CHECK_LAUNCH();
+      }
+      if (T > 1) {
+        RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 0.f));
+        RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 1.f));
+      }
+      const size_t last = (size_t)(T - 1) * B;
+      RETURN_IF(node_gemm_transposed(b, DPG + last * Np * 128, 128, WpG, I, 0, C, B, DAx, 0.f));
+      RETURN_IF(node_gemm_transposed(b, DPU + last * Np * 64, 64, WpU, I, 0, C, B, DAx, 1.f));
+      RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
+      RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
+      hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
+                         (size_t)B, Np, C, S);
       CHECK_LAUNCH();
     }
     {  // residual cell x columns
@@ -535,7 +564,9 @@ int backward_impl(Bwd& b, const float* dOut) {
       }
     }
     if (adp) {
-      RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, narrow));
+      if (narrow) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, true));
+      else if (l == 0) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
+      else RETURN_IF(adaptive_grad(bw, DAx, Xall + (size_t)(T - 1) * slab, B, C, dT));   // the other steps ride below
       RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
       RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
     }
