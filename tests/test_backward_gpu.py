@@ -302,3 +302,47 @@ def test_full_size_directional_derivative(lib_built):
         an = float((grads[name].double() * v.double()).sum())
         assert abs(fd - an) <= 2e-2 * max(abs(an), abs(fd)) + 1e-3, (name, fd, an)
     hp.prepare()
+
+
+@pytest.mark.parametrize("n,b", [(16, 70), (32, 5)])
+def test_backward_without_padding_nodes_and_ragged_batches(n, b, lib_built):
+    """N a multiple of 16 (no padding rows anywhere) and a batch that is not a multiple of the 64-row tile: a synthetic
+    case outside the golden set, HIP gradients vs fp64 autograd through the oracle"""
+    from multistgraph_amd import graph_prep, synthetic as syn
+    from multistgraph_amd.ops import HotPath, diagonal_mask, spec_from_config
+    from oracle import matgcn_oracle as orc
+    dev = torch.device("cuda:0")
+    df = syn.make_data_feature(n, 3, "DC", ext_dim=1)
+    cfg = dict(input_window=24, output_window=6, add_time_in_day=True, add_day_in_week=False, load_dynamic=False,
+               adjtype="multi", adpadj="unidirection", cheb_order=2, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
+               num_layers=2, device=torch.device("cpu"), batch_size=b)
+    mats = graph_prep.build_static_supports(df["adj_mx"], df["coordinate"], None, "multi")
+    st = torch.from_numpy(np.stack(mats, 0))
+    shapes = syn.param_shapes(n, out_steps=6, feat_in=2, k_total=5)
+    state_np = syn.closed_form_state(shapes, 3)
+    x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=2)
+    spec = spec_from_config(cfg, df, n, min(n, 20), 3, diagonal_mask(st))
+    hp = HotPath(spec, b, dev)
+    state = {k: torch.from_numpy(v).to(dev) for k, v in state_np.items()}
+    hp.bind(state, st.to(dev))
+    rng = np.random.default_rng(9)
+    d_out = rng.standard_normal((b, 6, n, 1)).astype(np.float32)
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state_np.items()}
+    ocfg = dict(adjtype="multi", adpadj="unidirection", cheb_order=2, num_layers=2, rnn_units=64, len_closeness=48,
+                len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=True,
+                add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=1)
+    y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [m.double() for m in st], ocfg, faithful=False)
+    (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
+    x = torch.from_numpy(x_np).to(dev)
+    got_y = hp.forward_train(x)
+    assert max_norm_err(got_y.cpu().numpy(), y.detach().numpy()) <= 1e-4
+    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state)
+    bad = {}
+    for k, v in p.items():
+        w = v.grad.numpy() if v.grad is not None else np.zeros(v.shape)
+        if np.abs(w).max() == 0.0:
+            if float(grads[k].abs().max()) > 1e-6:
+                bad[k] = "expected zero"
+        elif max_norm_err(grads[k].cpu().numpy(), w) > GRAD_TOL:
+            bad[k] = max_norm_err(grads[k].cpu().numpy(), w)
+    assert not bad, bad
