@@ -444,7 +444,10 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   // the mix of h_{t-1} doubles as the next layer's x-part mix of step t-1; otherwise training keeps the mixed rows of
   // every step in private per-step blocks (weight gradients of the backward)
   const bool shared = res && phase < 2 && shared_mix_slot(c, l, t - 1, &G, &gNodeStride);
-  if (!shared && c.train && res)
+  // (a layer that shares upwards has no private block for its recurrent mix: at t = 0, where nothing is shared, the
+  // mix of the zero state stays in the workspace - the backward knows it contributes nothing)
+  const bool sharesUp = !P.gcnOff && l + 1 < P.L && P.Ks > 0;
+  if (!shared && c.train && res && !(phase < 2 && sharesUp))
     G = c.train + (phase < 2 ? c.R.oGH[l] : c.R.oGZH[l]) + (size_t)t * P.N * P.B * P.Ks * H;
   float* R = c.ws + P.oR[l];
   if (phase == 0) return mix_rows(P, St, Hx, P.B, G, s, true, gNodeStride);
