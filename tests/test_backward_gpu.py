@@ -304,8 +304,12 @@ def test_full_size_directional_derivative(lib_built):
     hp.prepare()
 
 
-@pytest.mark.parametrize("n,b,layers", [(16, 70, 2), (32, 5, 2), (21, 3, 1), (21, 3, 3), (16, 2, 4)])
-def test_backward_without_padding_nodes_and_ragged_batches(n, b, layers, lib_built):
+@pytest.mark.parametrize("n,b,layers,flags", [
+    (16, 70, 2, {}), (32, 5, 2, {}), (21, 3, 1, {}), (21, 3, 3, {}), (16, 2, 4, {}), (21, 1, 2, {}),
+    (21, 2, 3, {"gcn_off": True}), (21, 2, 3, {"fnn_off": True}), (21, 2, 1, {"gcn_off": True, "fnn_off": True}),
+    (19, 2, 3, {"cheb_order": 3}),
+])
+def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags, lib_built):
     """N a multiple of 16 (no padding rows anywhere), a batch that is not a multiple of the 64-row tile, and 1 / 3 / 4
     encoder layers (the golden cases all have 2): synthetic cases outside the golden set, forward and HIP gradients vs
     fp64 autograd through the oracle"""
@@ -314,12 +318,15 @@ def test_backward_without_padding_nodes_and_ragged_batches(n, b, layers, lib_bui
     from oracle import matgcn_oracle as orc
     dev = torch.device("cuda:0")
     df = syn.make_data_feature(n, 3, "DC", ext_dim=1)
+    cheb = flags.get("cheb_order", 2)
+    abl = {k: v for k, v in flags.items() if k != "cheb_order"}
     cfg = dict(input_window=24, output_window=6, add_time_in_day=True, add_day_in_week=False, load_dynamic=False,
-               adjtype="multi", adpadj="unidirection", cheb_order=2, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
-               num_layers=layers, device=torch.device("cpu"), batch_size=b)
+               adjtype="multi", adpadj="unidirection", cheb_order=cheb, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
+               num_layers=layers, device=torch.device("cpu"), batch_size=b, **abl)
     mats = graph_prep.build_static_supports(df["adj_mx"], df["coordinate"], None, "multi")
     st = torch.from_numpy(np.stack(mats, 0))
-    shapes = syn.param_shapes(n, out_steps=6, feat_in=2, k_total=5, layers=layers)
+    shapes = syn.param_shapes(n, out_steps=6, feat_in=2, k_total=syn.k_total_for("multi", "unidirection", cheb),
+                              layers=layers, **abl)
     state_np = syn.closed_form_state(shapes, 3)
     x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=2)
     spec = spec_from_config(cfg, df, n, min(n, 20), 3, diagonal_mask(st))
@@ -329,9 +336,9 @@ def test_backward_without_padding_nodes_and_ragged_batches(n, b, layers, lib_bui
     rng = np.random.default_rng(9)
     d_out = rng.standard_normal((b, 6, n, 1)).astype(np.float32)
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state_np.items()}
-    ocfg = dict(adjtype="multi", adpadj="unidirection", cheb_order=2, num_layers=layers, rnn_units=64, len_closeness=48,
+    ocfg = dict(adjtype="multi", adpadj="unidirection", cheb_order=cheb, num_layers=layers, rnn_units=64, len_closeness=48,
                 len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=True,
-                add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=1)
+                add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=1, **abl)
     y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [m.double() for m in st], ocfg, faithful=False)
     (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
     x = torch.from_numpy(x_np).to(dev)
