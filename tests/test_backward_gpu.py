@@ -312,6 +312,7 @@ def test_full_size_directional_derivative(lib_built):
     (16, 3, 3, {"adjtype": "identity", "adpadj": "none", "cheb_order": 3}), (21, 2, 3, {"adjtype": "multi", "adpadj": "none"}),
     (21, 2, 3, {"adjtype": "cosine", "adpadj": "unidirection", "cheb_order": 3}),
     (21, 3, 2, {"end_dim": 2}),     # two flow channels: output_dim = 2 (MultiATGCN.py:320)
+    (21, 2, 2, {"ext": 8}),         # add_day_in_week: time of day + 7 day-of-week channels (:313-318)
 ])
 def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags, lib_built):
     """N a multiple of 16 (no padding rows anywhere), a batch that is not a multiple of the 64-row tile, and 1 / 3 / 4
@@ -323,19 +324,19 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     dev = torch.device("cuda:0")
     cheb = flags.get("cheb_order", 2)
     adjtype, adpadj = flags.get("adjtype", "multi"), flags.get("adpadj", "unidirection")
-    od = flags.get("end_dim", 1)
-    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim")}
-    cfg = dict(input_window=24, output_window=6, add_time_in_day=True, add_day_in_week=False, load_dynamic=False,
+    od, ext = flags.get("end_dim", 1), flags.get("ext", 1)
+    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext")}
+    cfg = dict(input_window=24, output_window=6, add_time_in_day=True, add_day_in_week=ext == 8, load_dynamic=False,
                adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
                num_layers=layers, device=torch.device("cpu"), batch_size=b, start_dim=0, end_dim=od, **abl)
-    df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=1), output_dim=od, feature_dim=od + 1)
+    df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=ext), output_dim=od, feature_dim=od + ext)
     mats = graph_prep.build_static_supports(df["adj_mx"], df["coordinate"], None, adjtype)
     use_static = adpadj == "none" or adjtype == "multi"
     st = torch.from_numpy(np.stack(mats, 0))
-    shapes = syn.param_shapes(n, out_steps=6, feat_in=od + 1, out_dim=od, k_total=syn.k_total_for(adjtype, adpadj, cheb),
+    shapes = syn.param_shapes(n, out_steps=6, feat_in=od + ext, out_dim=od, k_total=syn.k_total_for(adjtype, adpadj, cheb),
                               layers=layers, **abl)
     state_np = syn.closed_form_state(shapes, 3)
-    x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=od + 1)
+    x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=od + ext)
     if od > 1:   # channels [flow 0 .. flow od-1 | time of day]
         x_np = np.ascontiguousarray(np.concatenate([x_np[..., :1], x_np[..., 2:], x_np[..., 1:2]], -1))
     spec = spec_from_config(cfg, df, n, min(n, 20), st.shape[0] if use_static else 0,
@@ -348,7 +349,7 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state_np.items()}
     ocfg = dict(adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, num_layers=layers, rnn_units=64, len_closeness=48,
                 len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=True,
-                add_day_in_week=False, load_dynamic=False, start_dim=0, end_dim=od, **abl)
+                add_day_in_week=ext == 8, load_dynamic=False, start_dim=0, end_dim=od, **abl)
     y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [m.double() for m in st] if use_static else [], ocfg,
                     faithful=False)
     (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
