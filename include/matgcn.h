@@ -198,8 +198,8 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
  * matgcn_grads mirrors matgcn_params field by field (same shapes); every non-NULL gradient is OVERWRITTEN.
  * node_emb may be NULL (node_specific_off freezes it); node_vec1/2 are required iff adp_mode == UNI.
  * `train` is one more caller-owned device buffer of matgcn_train_bytes(): forward_train saves z, r, hc of the
- * graph cell and z2, r2, hc2 of the residual cell of every (layer, step) into it, backward uses the rest as
- * scratch.  matgcn_backward must see the SAME workspace and train buffers, untouched, that the matching
+ * graph cell, z2, r2, hc2 of the residual cell and the graph-mixed rows of every (layer, step) into it, backward uses
+ * the rest as scratch.  matgcn_backward must see the SAME workspace and train buffers, untouched, that the matching
  * matgcn_forward_train call used (the sequences of every layer live in the workspace).
  * d_out (B, output_window, N, output_dim) is the gradient of the loss w.r.t. the forward's output.
  * drop_mask: NULL (eval-mode forward), or the training-mode dropout in front of end_conv (MultiATGCN.py:416,
