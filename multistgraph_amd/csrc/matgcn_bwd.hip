@@ -192,24 +192,57 @@ int linear_weight_grad(const Bwd& b, const float* dPre, int O, const float* In, 
   return gemm(g, 1, b.c.s, BG_LINEAR);
 }
 
-int backward_impl(Bwd& b, const float* dOut) {
-  const Ctx& c = b.c;
-  const Plan& P = c.P;
-  const TrainPlan& R = c.R;
-  const matgcn_dims* D = c.D;
-  const matgcn_params* prm = c.prm;
-  const matgcn_grads* g = b.g;
-  float* tr = b.tr;
-  hipStream_t s = c.s;
-  const int S = R.S, T = P.T, B = P.B, Np = P.Np, N = P.N;
-  const long slab = (long)B * Np * H;
-  const int rowsTB = T * B;
-  if ((long)rowsTB * Np >= (1L << 31)) return MATGCN_ERR_UNSUPPORTED;
-  const bool adp = D->adp_mode != MATGCN_ADP_NONE && !P.gcnOff;
-  const int hT = P.headT, tOff = T - P.headT;     // fnn_off: the head sees the last step only (MultiATGCN.py:412)
-  // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
+// ---- one backward pass: what its stages share ---------------------------------------------------------------
+struct Pass {
+  Bwd b, bw;                 // bw: the same context on the second stream (weight gradients)
+  hipStream_t s, ws;
+  bool twoStreams, adp;
+  int hT, tOff;              // fnn_off: the head sees the last step only (MultiATGCN.py:412)
+  int fusedLds;
+  StackMap map;
+  int slotOf[MATGCN_MAX_STACK];
+};
 
-  // ---- scratch and outputs start from zero ----
+// per-layer views of the scratch (index l & 1: the weight gradients of layer l run on the second stream while the
+// chain of layer l-1 already fills the other set)
+struct LayerBufs {
+  int l, C, I, par;
+  const float* seq;          // Seq_l
+  float* dSeqCur;            // gradient of Seq_l
+  float* dXall;              // gradient of the layer's input sequence (dSeq of the layer below / dX0)
+  float *DPU, *DPG, *DPU2, *DPG2, *DAg, *DAu, *DAx;
+  const float *WpG, *WpU, *RG, *RU;
+  bool mergeAbove;           // the gate block already holds the x-column gradient of the layer above
+  bool narrow;               // layer 0 with a handful of input channels
+};
+
+#define PASS_LOCALS(q)                                                                                             \
+  [[maybe_unused]] const Bwd& b = (q).b; [[maybe_unused]] const Bwd& bw = (q).bw;                                   \
+  [[maybe_unused]] const Ctx& c = (q).b.c; [[maybe_unused]] const Plan& P = (q).b.c.P;                              \
+  [[maybe_unused]] const TrainPlan& R = (q).b.c.R; [[maybe_unused]] const matgcn_dims* D = (q).b.c.D;               \
+  [[maybe_unused]] const matgcn_params* prm = (q).b.c.prm; [[maybe_unused]] const matgcn_grads* g = (q).b.g;        \
+  [[maybe_unused]] float* tr = (q).b.tr; [[maybe_unused]] hipStream_t s = (q).s; [[maybe_unused]] hipStream_t ws = (q).ws; \
+  [[maybe_unused]] const int S = R.S, T = P.T, B = P.B, Np = P.Np, N = P.N;                                         \
+  [[maybe_unused]] const long slab = (long)B * Np * H; [[maybe_unused]] const int rowsTB = T * B;                   \
+  [[maybe_unused]] const bool twoStreams = (q).twoStreams, adp = (q).adp;                                           \
+  [[maybe_unused]] const int hT = (q).hT, tOff = (q).tOff, fusedLds = (q).fusedLds;                                 \
+  [[maybe_unused]] const StackMap& map = (q).map; [[maybe_unused]] const int* slotOf = (q).slotOf;                  \
+  [[maybe_unused]] float* dT = tr + R.oDT
+
+#define LAYER_LOCALS(L)                                                                                            \
+  [[maybe_unused]] const int l = (L).l, C = (L).C, I = (L).I, par = (L).par;                                        \
+  [[maybe_unused]] const float* seq = (L).seq; [[maybe_unused]] float* dSeqCur = (L).dSeqCur;                       \
+  [[maybe_unused]] float* dXall = (L).dXall;                                                                        \
+  [[maybe_unused]] float *DPU = (L).DPU, *DPG = (L).DPG, *DPU2 = (L).DPU2, *DPG2 = (L).DPG2, *DAg = (L).DAg,        \
+                         *DAu = (L).DAu, *DAx = (L).DAx;                                                            \
+  [[maybe_unused]] const float *WpG = (L).WpG, *WpU = (L).WpU, *RG = (L).RG, *RU = (L).RU;                          \
+  [[maybe_unused]] const bool mergeAbove = (L).mergeAbove, narrow = (L).narrow;                                     \
+  [[maybe_unused]] float* DH = tr + R.oDH; [[maybe_unused]] float* DHa = tr + R.oDHa;                               \
+  [[maybe_unused]] float* TMP = tr + R.oTmp; [[maybe_unused]] float* MixOut = tr + R.oMixOut
+
+// scratch and outputs start from zero (only what is accumulated into, or what the GEMMs leave untouched)
+int bwd_clear(Pass& pass) {
+  PASS_LOCALS(pass);
   // (only what is accumulated into, or what the GEMMs leave untouched: the rows of the padding nodes)
   for (int l = 0; l < P.L; ++l)
     for (int part = 0; part < 2; ++part) {
@@ -241,10 +274,12 @@ int backward_impl(Bwd& b, const float* dOut) {
   if ((!P.gcnOff && !g->weights_gru) || !g->weight_tsg || !g->end_conv_weight || !g->end_conv_bias)
     return MATGCN_ERR_NULL;
 
-  const StackMap map = build_stack_map(P, D, prm);
-  int slotOf[MATGCN_MAX_STACK];
-  slot_map(P, map, slotOf);
+  return MATGCN_OK;
+}
 
+// plain copies the backward GEMMs contract with: the support stack and the folded node-adaptive weights
+int bwd_plain_operands(Pass& pass) {
+  PASS_LOCALS(pass);
   if (P.Ks > 0) {  // plain copy of the support stack for the transposed mixes
     hipLaunchKernelGGL(k_stack_plain, dim3((unsigned)((P.Ks * Np + 31) / 32), (unsigned)((P.NpC + 31) / 32)), dim3(256),
                        0, s, c.prep + P.oSt, P.Mp, N, P.Ks * Np, P.NpC, tr + R.oStP);
@@ -263,6 +298,11 @@ int backward_impl(Bwd& b, const float* dOut) {
       CHECK_LAUNCH();
     }
 
+  return MATGCN_OK;
+}
+
+int bwd_head(Pass& pass, const float* dOut) {
+  PASS_LOCALS(pass);
   // ---- output head (MultiATGCN.py:416-418) ----
   float* dOutRows = tr + R.oDOutRows;
   hipLaunchKernelGGL(k_dout_rows, dim3(blocks_for((size_t)B * Np * P.CH)), dim3(256), 0, s, dOut, dOutRows, B,
@@ -297,310 +337,297 @@ int backward_impl(Bwd& b, const float* dOut) {
     }
   }
 
-  float* dT = tr + R.oDT;
-  // the weight gradients of a layer (big GEMMs) run on a library stream while the caller's stream already walks the
-  // chain of the layer below (small dependent launches); matgcn_set_wavefront(0) keeps everything on one stream
-  RETURN_IF(wavefront_ready());
-  const int fusedLds = 128 * CF_LD * (int)sizeof(float);
+  return MATGCN_OK;
+}
+
+// gcn_off: a layer of dense GRU cells
+int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
   {
-    static bool optedIn = false;   // dynamic LDS above 64 KB must be opted into once
-    if (!optedIn) {
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, fusedLds));
-      optedIn = true;
-    }
-  }
-  const bool twoStreams = g_wavefront_mode != 0 && P.L > 1 && !P.gcnOff;
-  hipStream_t ws = twoStreams ? g_wf.chain[1] : s;
-  Bwd bw = b;
-  bw.c.s = ws;
-  int cur = 0;
-  for (int l = P.L - 1; l >= 0; --l) {
-    const int C = P.Cl[l], I = C + H;
-    const int par = P.L > 1 ? (l & 1) : 0;
-    const float* seq = c.ws + P.oSeq[l];
-    float* dSeqCur = tr + R.oDSeq[cur];
-    if (twoStreams && l + 2 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 2], 0));   // scratch set is free again
-    float* DPU = tr + R.oDPU[par]; float* DPG = tr + R.oDPG[par];
-    float* DPU2 = tr + R.oDPU2[par]; float* DPG2 = tr + R.oDPG2[par];
-    float* DAg = tr + R.oDAg[par]; float* DAu = tr + R.oDAu[par];
-    float* DH = tr + R.oDH; float* DHa = tr + R.oDHa; float* TMP = tr + R.oTmp; float* MixOut = tr + R.oMixOut;
-    const float* WpG = tr + R.oWp[l][0];
-    const float* WpU = tr + R.oWp[l][1];
-    const float* RG = prm->res_gate[l].weight;     // (128, I)
-    const float* RU = prm->res_update[l].weight;   // (64, I)
-    // x_t of layer l+1 IS h_t of layer l: the gradient of [x | mix(x)] of the layer above (steps 0..T-2) was written
-    // into this layer's gate block of step t+1 and is back-propagated together with it
-    const bool mergeAbove = !P.gcnOff && l + 1 < P.L;
-    if (P.gcnOff) {
-      // ablation: the layer is one dense GRU cell per step on (x_t, h) (MultiATGCN.py:142-150,187-192,204); its
-      // nn.Linear parameters travel in the res_* fields.  z, r, hc were saved in the residual-cell slots.
-      float* carry[2] = {DH, DHa};
-      for (int t = T - 1; t >= 0; --t) {
-        const size_t at = (size_t)t * slab;
-        ChainArgs a;
-        memset(&a, 0, sizeof(a));
-        a.dense = 1;
-        a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : carry[(t + 1) & 1];
-        a.hprev = t > 0 ? seq + at - slab : nullptr;
-        a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
-        a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR;
-        a.B = B; a.N = N; a.Np = Np; a.S = S;
-        const dim3 eg(blocks_for((size_t)slab));
-        hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
-        CHECK_LAUNCH();
-        GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
-        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
-        hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
-        CHECK_LAUNCH();
-        GemmArgs q2 = gemm_args(DPG2 + 2 * at, RG + C, carry[t & 1], B * Np, H, 128);
-        q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = H; q2.sCn = 1; q2.beta = 1.f;
-        RETURN_IF(gemm(q2, 1, s, BG_CHAIN_DENSE));
-      }
-      const float* Xall;
-      if (l == 0) {
-        float* X0tm = tr + R.oX0tm;
-        hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, s,
-                           c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
-        CHECK_LAUNCH();
-        Xall = X0tm;
-      } else {
-        Xall = c.ws + P.oSeq[l - 1];
-      }
-      float* Hprev = tr + R.oHprev[par]; float* Z2H = tr + R.oZ2HA[par];
-      RETURN_IF(zero_async(Hprev, slab, s));
-      if (T > 1)
-        HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
-      const size_t seqN = (size_t)T * slab;
-      hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oZ2[l], Hprev, Z2H, seqN);
-      CHECK_LAUNCH();
-      float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
-      {
-        GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
-        q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s, BG_X_NODE));
-        GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
-        q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
-        RETURN_IF(gemm(q2, 1, s, BG_X_NODE));
-      }
-      const matgcn_linear_grads& gg = g->res_gate[l];
-      const matgcn_linear_grads& gu = g->res_update[l];
-      if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
-      RETURN_IF(zero_async(gg.weight, 128L * I, s));
-      RETURN_IF(zero_async(gu.weight, 64L * I, s));
-      const long rows = (long)rowsTB * Np;
-      RETURN_IF(linear_weight_grad(b, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
-      RETURN_IF(linear_weight_grad(b, DPG2, 128, Hprev, H, rows, I, C, gg.weight));
-      RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
-      RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2H, H, rows, I, C, gu.weight));
-      RETURN_IF(zero_async(gg.bias, 128, s));
-      RETURN_IF(zero_async(gu.bias, 64, s));
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
-      CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
-      CHECK_LAUNCH();
-      if (l > 0) cur ^= 1;
-      continue;
-    }
-    // ---------------- chain ----------------
+    // ablation: the layer is one dense GRU cell per step on (x_t, h) (MultiATGCN.py:142-150,187-192,204); its
+    // nn.Linear parameters travel in the res_* fields.  z, r, hc were saved in the residual-cell slots.
+    float* carry[2] = {DH, DHa};
     for (int t = T - 1; t >= 0; --t) {
       const size_t at = (size_t)t * slab;
       ChainArgs a;
       memset(&a, 0, sizeof(a));
-      a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : DH; a.hprev = t > 0 ? seq + at - slab : nullptr;
-      a.z = tr + R.oZ[l] + at; a.r = tr + R.oR[l] + at; a.hc = tr + R.oHC[l] + at;
+      a.dense = 1;
+      a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : carry[(t + 1) & 1];
+      a.hprev = t > 0 ? seq + at - slab : nullptr;
       a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
-      a.blend = prm->weights_gru + (size_t)l * T + t; a.dblend = g->weights_gru + (size_t)l * T + t;
-      a.dha = DHa; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dpu = DPU + at; a.dpg = DPG + 2 * at;
-      a.dzh2 = TMP; a.dzhA = DAu + at * S; a.dzhMix = P.Ks > 0 ? MixOut : nullptr;
-      a.dhA = DAg + at * S; a.dhMix = P.Ks > 0 ? MixOut : nullptr;
-      a.dh = DH; a.dr = tr + R.oDR;
+      a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR;
       a.B = B; a.N = N; a.Np = Np; a.S = S;
       const dim3 eg(blocks_for((size_t)slab));
-      {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
-        FusedResArgs f;
-        f.c = a;
-        f.c.dcarry = (t == T - 1) ? nullptr : DH;
-        f.carryA = (t == T - 1) ? nullptr : DAg + (at + slab) * S;
-        f.carryMix = (t == T - 1 || P.Ks <= 0) ? nullptr : MixOut;
-        f.ruh = RU + C; f.rgh = RG + C; f.ldW = I;
-        hipLaunchKernelGGL(k_chain_res_fused, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
-        CHECK_LAUNCH();
-      }
-      RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
-      RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
-      hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
       CHECK_LAUNCH();
-      // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
-      // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
-      RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
-      RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
-    }
-    // ---------------- everything that batches over the T steps ----------------
-    // x columns of both AGCNs -> gradient of the input sequence of this layer
-    float* DAx = tr + R.oDAx[par];
-    const bool narrow = C != H;   // layer 0: a handful of input channels
-    float* dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
-    if (narrow) {
-      // node-major [s][n][rows][C]: the transposed mix is one GEMM with rows*C columns
-      RETURN_IF(zero_async(DAx, (long)rowsTB * S * Np * C, s));
-      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f, true));
-      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f, true));
-      const long cols = (long)rowsTB * C;
-      float* MixN = tr + R.oMixN;
-      if (P.Ks > 0) {
-        GemmArgs q = gemm_args(c.prep + P.oSt, DAx + (size_t)Np * cols, MixN, N, (int)cols, P.Ks * Np);
-        q.sAm = P.Mp; q.sAk = 1; q.sBk = cols; q.sBn = 1; q.sCm = cols; q.sCn = 1;
-        RETURN_IF(gemm(q, 1, s, BG_X_MIX));
-      }
-      hipLaunchKernelGGL(k_narrow_gather, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s,
-                         P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
+      GemmArgs q = gemm_args(DPU2 + at, RU + C, TMP, B * Np, H, H);
+      q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = H; q.sCn = 1;
+      RETURN_IF(gemm(q, 1, s, BG_CHAIN_DENSE));
+      hipLaunchKernelGGL(k_chain_res_gate, eg, dim3(256), 0, s, a);
       CHECK_LAUNCH();
-    } else if (l == 0) {   // a 64-channel input layer: nothing below to ride with
-      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
-      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
-      RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
-      RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
-      hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
-                         (size_t)rowsTB, Np, C, S);
-      CHECK_LAUNCH();
-    } else {
-      // layers >= 1: steps 0..T-2 go into the gate block of the layer below at step t+1 (see mergeAbove); only the
-      // sequence's last step, which no step of the layer below follows, is mixed back here
-      const int parBelow = (l - 1) & 1;
-      float* DAgBelow = tr + R.oDAg[parBelow];
-      if (twoStreams && l + 1 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 1], 0));   // its readers are done
-      RETURN_IF(zero_async(DAgBelow, slab * S, s));                                         // step 0: nothing from above
-      if (Np != N) {
-        hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)B * S * (Np - N) * H)), dim3(256), 0, s, DAx, B * S, N, Np,
-                           H);
-        CHECK_LAUNCH();
-      }
-      if (T > 1) {
-        RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 0.f));
-        RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 1.f));
-      }
-      const size_t last = (size_t)(T - 1) * B;
-      RETURN_IF(node_gemm_transposed(b, DPG + last * Np * 128, 128, WpG, I, 0, C, B, DAx, 0.f));
-      RETURN_IF(node_gemm_transposed(b, DPU + last * Np * 64, 64, WpU, I, 0, C, B, DAx, 1.f));
-      RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
-      RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
-      hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
-                         (size_t)B, Np, C, S);
-      CHECK_LAUNCH();
-    }
-    {  // residual cell x columns
-      GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
-      q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
-      RETURN_IF(gemm(q, 1, s));
-      GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
-      q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
-      RETURN_IF(gemm(q2, 1, s));
-    }
-    // ---- from here on: the layer's weight gradients, on the second stream ----
-    if (twoStreams) {
-      HIP_OK(hipEventRecord(g_wf.step[0][l], s));
-      HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
+      GemmArgs q2 = gemm_args(DPG2 + 2 * at, RG + C, carry[t & 1], B * Np, H, 128);
+      q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = H; q2.sCn = 1; q2.beta = 1.f;
+      RETURN_IF(gemm(q2, 1, s, BG_CHAIN_DENSE));
     }
     const float* Xall;
     if (l == 0) {
       float* X0tm = tr + R.oX0tm;
-      hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, ws,
+      hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, s,
                          c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
       CHECK_LAUNCH();
       Xall = X0tm;
     } else {
       Xall = c.ws + P.oSeq[l - 1];
     }
-    float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
-    float* Z2HA = tr + R.oZ2HA[par];
-    RETURN_IF(zero_async(Hprev, slab, ws));
+    float* Hprev = tr + R.oHprev[par]; float* Z2H = tr + R.oZ2HA[par];
+    RETURN_IF(zero_async(Hprev, slab, s));
     if (T > 1)
-      HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
+      HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t seqN = (size_t)T * slab;
-    hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oZ[l], Hprev, ZH, seqN);
+    hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, s, tr + R.oZ2[l], Hprev, Z2H, seqN);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oR[l], Hprev, tr + R.oHC[l],
-                       tr + R.oZ2[l], HA, Z2HA, seqN);
-    CHECK_LAUNCH();
-    // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
-    float* dWpG = tr + R.oDWp[l][0];
-    float* dWpU = tr + R.oDWp[l][1];
-    const long gStep = (long)N * B * P.Ks * H;
-    if (l + 1 < P.L && P.Ks > 0) {
-      // the mix of h_{t-1} was written into the chunk blocks of the layer above (its x-part mix of step t-1, see
-      // shared_mix_slot): identity slot over all rows, dense slots chunk by chunk, shifted by one step; the mix of
-      // the zero state at t = 0 contributes nothing
-      MixedRows none = {nullptr, 0, 0, 0, 0, 0, 0};
-      RETURN_IF(node_weight_grad(bw, Hprev, none, H, DPG, 128, I, C, 0, rowsTB, dWpG, 1));
-      for (int t0 = 0; t0 < T;) {
-        const int nt = chunk_steps(P, t0);
-        const int ntm = T - 1 - t0 < nt ? T - 1 - t0 : nt;   // the block's last slot of the sequence feeds nobody here
-        MixedRows mh = {tr + R.oGX[l + 1] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, ntm * B};
-        RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, (long)(t0 + 1) * B, ntm * B, dWpG, 2));
-        t0 += nt;
-      }
-    } else {  // recurrent rows of the top layer: private blocks [T][N][B][Ks][64]
-      MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
-      RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
-    }
     {
-      MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
-      RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
+      GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
+      q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1;
+      RETURN_IF(gemm(q, 1, s, BG_X_NODE));
+      GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
+      q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
+      RETURN_IF(gemm(q2, 1, s, BG_X_NODE));
     }
-    if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
-      const long ld = rup((long)rowsTB * P.C0, 64);
-      MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
-      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
-      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
-    } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
-      for (int t0 = 0; t0 < T;) {
-        const int nt = chunk_steps(P, t0);
-        MixedRows mx = {tr + R.oGX[l] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, nt * B};
-        RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, (long)t0 * B, nt * B, dWpG));
-        RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, (long)t0 * B, nt * B, dWpU));
-        t0 += nt;
-      }
-    }
-    if (adp) {
-      if (narrow) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, true));
-      else if (l == 0) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
-      else RETURN_IF(adaptive_grad(bw, DAx, Xall + (size_t)(T - 1) * slab, B, C, dT));   // the other steps ride below
-      RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
-      RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
-    }
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
-                       Np, 128, tr + R.oDBias[l][0]);
+    const matgcn_linear_grads& gg = g->res_gate[l];
+    const matgcn_linear_grads& gu = g->res_update[l];
+    if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
+    RETURN_IF(zero_async(gg.weight, 128L * I, s));
+    RETURN_IF(zero_async(gu.weight, 64L * I, s));
+    const long rows = (long)rowsTB * Np;
+    RETURN_IF(linear_weight_grad(b, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+    RETURN_IF(linear_weight_grad(b, DPG2, 128, Hprev, H, rows, I, C, gg.weight));
+    RETURN_IF(linear_weight_grad(b, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+    RETURN_IF(linear_weight_grad(b, DPU2, 64, Z2H, H, rows, I, C, gu.weight));
+    RETURN_IF(zero_async(gg.bias, 128, s));
+    RETURN_IF(zero_async(gu.bias, 64, s));
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
     CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
-                       64, tr + R.oDBias[l][1]);
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, s, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
     CHECK_LAUNCH();
-    // residual nn.Linear gradients (MultiATGCN.py:139-150)
-    {
-      const matgcn_linear_grads& gg = g->res_gate[l];
-      const matgcn_linear_grads& gu = g->res_update[l];
-      if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
-      RETURN_IF(zero_async(gg.weight, 128L * I, ws));
-      RETURN_IF(zero_async(gu.weight, 64L * I, ws));
-      const long rows = (long)rowsTB * Np;
-      RETURN_IF(linear_weight_grad(bw, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
-      RETURN_IF(linear_weight_grad(bw, DPG2, 128, HA, H, rows, I, C, gg.weight));
-      RETURN_IF(linear_weight_grad(bw, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
-      RETURN_IF(linear_weight_grad(bw, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
-      RETURN_IF(zero_async(gg.bias, 128, ws));
-      RETURN_IF(zero_async(gu.bias, 64, ws));
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
-      CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
-      CHECK_LAUNCH();
-    }
-    if (twoStreams) HIP_OK(hipEventRecord(g_wf.step[1][l], ws));
-    if (l > 0) cur ^= 1;
   }
-  if (twoStreams)
-    for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l], 0));   // join
+  return MATGCN_OK;
+}
 
+// the part of a graph layer that is sequential in time
+int bwd_chain(Pass& pass, const LayerBufs& L) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  // ---------------- chain ----------------
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t at = (size_t)t * slab;
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : DH; a.hprev = t > 0 ? seq + at - slab : nullptr;
+    a.z = tr + R.oZ[l] + at; a.r = tr + R.oR[l] + at; a.hc = tr + R.oHC[l] + at;
+    a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
+    a.blend = prm->weights_gru + (size_t)l * T + t; a.dblend = g->weights_gru + (size_t)l * T + t;
+    a.dha = DHa; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dpu = DPU + at; a.dpg = DPG + 2 * at;
+    a.dzh2 = TMP; a.dzhA = DAu + at * S; a.dzhMix = P.Ks > 0 ? MixOut : nullptr;
+    a.dhA = DAg + at * S; a.dhMix = P.Ks > 0 ? MixOut : nullptr;
+    a.dh = DH; a.dr = tr + R.oDR;
+    a.B = B; a.N = N; a.Np = Np; a.S = S;
+    const dim3 eg(blocks_for((size_t)slab));
+    {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
+      FusedResArgs f;
+      f.c = a;
+      f.c.dcarry = (t == T - 1) ? nullptr : DH;
+      f.carryA = (t == T - 1) ? nullptr : DAg + (at + slab) * S;
+      f.carryMix = (t == T - 1 || P.Ks <= 0) ? nullptr : MixOut;
+      f.ruh = RU + C; f.rgh = RG + C; f.ldW = I;
+      hipLaunchKernelGGL(k_chain_res_fused, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
+      CHECK_LAUNCH();
+    }
+    RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
+    RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
+    hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
+    CHECK_LAUNCH();
+    // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
+    // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
+    RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
+    RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
+  }
+  return MATGCN_OK;
+}
+
+// x columns of both AGCNs and of the residual cell -> gradient of the layer's input sequence
+int bwd_x_columns(Pass& pass, const LayerBufs& L) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  // ---------------- everything that batches over the T steps ----------------
+  // x columns of both AGCNs -> gradient of the input sequence of this layer
+  if (narrow) {
+    // node-major [s][n][rows][C]: the transposed mix is one GEMM with rows*C columns
+    RETURN_IF(zero_async(DAx, (long)rowsTB * S * Np * C, s));
+    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f, true));
+    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f, true));
+    const long cols = (long)rowsTB * C;
+    float* MixN = tr + R.oMixN;
+    if (P.Ks > 0) {
+      GemmArgs q = gemm_args(c.prep + P.oSt, DAx + (size_t)Np * cols, MixN, N, (int)cols, P.Ks * Np);
+      q.sAm = P.Mp; q.sAk = 1; q.sBk = cols; q.sBn = 1; q.sCm = cols; q.sCn = 1;
+      RETURN_IF(gemm(q, 1, s, BG_X_MIX));
+    }
+    hipLaunchKernelGGL(k_narrow_gather, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s,
+                       P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
+    CHECK_LAUNCH();
+  } else if (l == 0) {   // a 64-channel input layer: nothing below to ride with
+    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
+    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
+    RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
+    RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
+    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
+                       (size_t)rowsTB, Np, C, S);
+    CHECK_LAUNCH();
+  } else {
+    // layers >= 1: steps 0..T-2 go into the gate block of the layer below at step t+1 (see mergeAbove); only the
+    // sequence's last step, which no step of the layer below follows, is mixed back here
+    const int parBelow = (l - 1) & 1;
+    float* DAgBelow = tr + R.oDAg[parBelow];
+    if (twoStreams && l + 1 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 1], 0));   // its readers are done
+    RETURN_IF(zero_async(DAgBelow, slab * S, s));                                         // step 0: nothing from above
+    if (Np != N) {
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)B * S * (Np - N) * H)), dim3(256), 0, s, DAx, B * S, N, Np,
+                         H);
+      CHECK_LAUNCH();
+    }
+    if (T > 1) {
+      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 0.f));
+      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 1.f));
+    }
+    const size_t last = (size_t)(T - 1) * B;
+    RETURN_IF(node_gemm_transposed(b, DPG + last * Np * 128, 128, WpG, I, 0, C, B, DAx, 0.f));
+    RETURN_IF(node_gemm_transposed(b, DPU + last * Np * 64, 64, WpU, I, 0, C, B, DAx, 1.f));
+    RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
+    RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
+    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
+                       (size_t)B, Np, C, S);
+    CHECK_LAUNCH();
+  }
+  {  // residual cell x columns
+    GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
+    q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
+    RETURN_IF(gemm(q, 1, s));
+    GemmArgs q2 = gemm_args(DPG2, RG, dXall, rowsTB * Np, C, 128);
+    q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
+    RETURN_IF(gemm(q2, 1, s));
+  }
+  return MATGCN_OK;
+}
+
+// weight gradients of a graph layer (on the second stream when there is one)
+int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  // ---- from here on: the layer's weight gradients, on the second stream ----
+  if (twoStreams) {
+    HIP_OK(hipEventRecord(g_wf.step[0][l], s));
+    HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
+  }
+  const float* Xall;
+  if (l == 0) {
+    float* X0tm = tr + R.oX0tm;
+    hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, ws,
+                       c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
+    CHECK_LAUNCH();
+    Xall = X0tm;
+  } else {
+    Xall = c.ws + P.oSeq[l - 1];
+  }
+  float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
+  float* Z2HA = tr + R.oZ2HA[par];
+  RETURN_IF(zero_async(Hprev, slab, ws));
+  if (T > 1)
+    HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
+  const size_t seqN = (size_t)T * slab;
+  hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oZ[l], Hprev, ZH, seqN);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oR[l], Hprev, tr + R.oHC[l],
+                     tr + R.oZ2[l], HA, Z2HA, seqN);
+  CHECK_LAUNCH();
+  // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
+  float* dWpG = tr + R.oDWp[l][0];
+  float* dWpU = tr + R.oDWp[l][1];
+  const long gStep = (long)N * B * P.Ks * H;
+  if (l + 1 < P.L && P.Ks > 0) {
+    // the mix of h_{t-1} was written into the chunk blocks of the layer above (its x-part mix of step t-1, see
+    // shared_mix_slot): identity slot over all rows, dense slots chunk by chunk, shifted by one step; the mix of
+    // the zero state at t = 0 contributes nothing
+    MixedRows none = {nullptr, 0, 0, 0, 0, 0, 0};
+    RETURN_IF(node_weight_grad(bw, Hprev, none, H, DPG, 128, I, C, 0, rowsTB, dWpG, 1));
+    for (int t0 = 0; t0 < T;) {
+      const int nt = chunk_steps(P, t0);
+      const int ntm = T - 1 - t0 < nt ? T - 1 - t0 : nt;   // the block's last slot of the sequence feeds nobody here
+      MixedRows mh = {tr + R.oGX[l + 1] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, ntm * B};
+      RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, (long)(t0 + 1) * B, ntm * B, dWpG, 2));
+      t0 += nt;
+    }
+  } else {  // recurrent rows of the top layer: private blocks [T][N][B][Ks][64]
+    MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
+    RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
+  }
+  {
+    MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
+    RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
+  }
+  if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
+    const long ld = rup((long)rowsTB * P.C0, 64);
+    MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
+    RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
+    RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
+  } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
+    for (int t0 = 0; t0 < T;) {
+      const int nt = chunk_steps(P, t0);
+      MixedRows mx = {tr + R.oGX[l] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, nt * B};
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, (long)t0 * B, nt * B, dWpG));
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, (long)t0 * B, nt * B, dWpU));
+      t0 += nt;
+    }
+  }
+  if (adp) {
+    if (narrow) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, true));
+    else if (l == 0) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
+    else RETURN_IF(adaptive_grad(bw, DAx, Xall + (size_t)(T - 1) * slab, B, C, dT));   // the other steps ride below
+    RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
+    RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
+  }
+  hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
+                     Np, 128, tr + R.oDBias[l][0]);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
+                     64, tr + R.oDBias[l][1]);
+  CHECK_LAUNCH();
+  // residual nn.Linear gradients (MultiATGCN.py:139-150)
+  {
+    const matgcn_linear_grads& gg = g->res_gate[l];
+    const matgcn_linear_grads& gu = g->res_update[l];
+    if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
+    RETURN_IF(zero_async(gg.weight, 128L * I, ws));
+    RETURN_IF(zero_async(gu.weight, 64L * I, ws));
+    const long rows = (long)rowsTB * Np;
+    RETURN_IF(linear_weight_grad(bw, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+    RETURN_IF(linear_weight_grad(bw, DPG2, 128, HA, H, rows, I, C, gg.weight));
+    RETURN_IF(linear_weight_grad(bw, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+    RETURN_IF(linear_weight_grad(bw, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
+    RETURN_IF(zero_async(gg.bias, 128, ws));
+    RETURN_IF(zero_async(gu.bias, 64, ws));
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
+    CHECK_LAUNCH();
+  }
+  if (twoStreams) HIP_OK(hipEventRecord(g_wf.step[1][l], ws));
+  return MATGCN_OK;
+}
+
+int bwd_fuse_heads(Pass& pass) {
+  PASS_LOCALS(pass);
   // ---- head fusion (MultiATGCN.py:365-402) ----
   {
     float* dgain = tr + R.oDGain;
@@ -621,6 +648,11 @@ int backward_impl(Bwd& b, const float* dOut) {
     CHECK_LAUNCH();
   }
 
+  return MATGCN_OK;
+}
+
+int bwd_pools(Pass& pass) {
+  PASS_LOCALS(pass);
   // ---- parameter-only part: node-adaptive weights -> pools, node_emb, weights_g (MultiATGCN.py:102-105) ----
   float* EK = tr + R.oEK; float* FK = tr + R.oFK; float* TmpK = tr + R.oTmpK; float* dgain = tr + R.oDGain;
   const int Kt = P.KtotOrig;
@@ -668,6 +700,11 @@ int backward_impl(Bwd& b, const float* dOut) {
       }
     }
 
+  return MATGCN_OK;
+}
+
+int bwd_adaptive_adjacency(Pass& pass) {
+  PASS_LOCALS(pass);
   // ---- adaptive adjacency (MultiATGCN.py:80-83) ----
   if (adp) {
     // Chebyshev orders of the adaptive adjacency A: T_o = 2 A T_{o-1} - T_{o-2} (MultiATGCN.py:98-99), back to A:
@@ -712,6 +749,72 @@ int backward_impl(Bwd& b, const float* dOut) {
     }
   }
   return MATGCN_OK;
+}
+
+int backward_impl(Bwd& b, const float* dOut) {
+  const Plan& P = b.c.P;
+  const TrainPlan& R = b.c.R;
+  float* tr = b.tr;
+  if ((long)P.T * P.B * P.Np >= (1L << 31)) return MATGCN_ERR_UNSUPPORTED;
+  Pass q;
+  q.b = b;
+  q.s = b.c.s;
+  // the adaptive adjacency is first-order support 0 and never diagonal: it is dense slot 0 (node-GEMM slot 1)
+  q.adp = b.c.D->adp_mode != MATGCN_ADP_NONE && !P.gcnOff;
+  q.hT = P.headT; q.tOff = P.T - P.headT;
+  q.map = build_stack_map(P, b.c.D, b.c.prm);
+  slot_map(P, q.map, q.slotOf);
+  // the weight gradients of a layer (big GEMMs) run on a library stream while the caller's stream already walks the
+  // chain of the layer below (small dependent launches); matgcn_set_wavefront(0) keeps everything on one stream
+  RETURN_IF(wavefront_ready());
+  q.fusedLds = 128 * CF_LD * (int)sizeof(float);
+  {
+    static bool optedIn = false;   // dynamic LDS above 64 KB must be opted into once
+    if (!optedIn) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, q.fusedLds));
+      optedIn = true;
+    }
+  }
+  q.twoStreams = g_wavefront_mode != 0 && P.L > 1 && !P.gcnOff;
+  q.ws = q.twoStreams ? g_wf.chain[1] : q.s;
+  q.bw = b;
+  q.bw.c.s = q.ws;
+
+  RETURN_IF(bwd_clear(q));
+  RETURN_IF(bwd_plain_operands(q));
+  RETURN_IF(bwd_head(q, dOut));
+  int cur = 0;   // which of the two sequence-gradient buffers holds the gradient of the current layer's output
+  for (int l = P.L - 1; l >= 0; --l) {
+    LayerBufs L;
+    L.l = l; L.C = P.Cl[l]; L.I = L.C + H; L.par = P.L > 1 ? (l & 1) : 0;
+    L.seq = b.c.ws + P.oSeq[l];
+    L.dSeqCur = tr + R.oDSeq[cur];
+    L.dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
+    L.DPU = tr + R.oDPU[L.par]; L.DPG = tr + R.oDPG[L.par]; L.DPU2 = tr + R.oDPU2[L.par]; L.DPG2 = tr + R.oDPG2[L.par];
+    L.DAg = tr + R.oDAg[L.par]; L.DAu = tr + R.oDAu[L.par]; L.DAx = tr + R.oDAx[L.par];
+    L.WpG = tr + R.oWp[l][0]; L.WpU = tr + R.oWp[l][1];
+    L.RG = b.c.prm->res_gate[l].weight;     // (128, I)
+    L.RU = b.c.prm->res_update[l].weight;   // (64, I)
+    // x_t of layer l+1 IS h_t of layer l: the gradient of [x | mix(x)] of the layer above (steps 0..T-2) was written
+    // into this layer's gate block of step t+1 and is back-propagated together with it
+    L.mergeAbove = !P.gcnOff && l + 1 < P.L;
+    L.narrow = L.C != H;   // layer 0: a handful of input channels
+    if (q.twoStreams && l + 2 < P.L) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l + 2], 0));   // scratch set is free again
+    if (P.gcnOff) {
+      RETURN_IF(bwd_dense_layer(q, L));
+    } else {
+      RETURN_IF(bwd_chain(q, L));
+      RETURN_IF(bwd_x_columns(q, L));
+      RETURN_IF(bwd_layer_weights(q, L));
+    }
+    if (l > 0) cur ^= 1;
+  }
+  if (q.twoStreams)
+    for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l], 0));   // join
+  RETURN_IF(bwd_fuse_heads(q));
+  RETURN_IF(bwd_pools(q));
+  return bwd_adaptive_adjacency(q);
 }
 
 }  // namespace
