@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
       scale[s] = 1.f;
     }
   }
+#pragma unroll 4
   for (int dd = 0; dd < a.d; ++dd) {
     float pv[4];
 #pragma unroll
