@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 7
+#define MATGCN_ABI_VERSION 8
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -186,11 +186,18 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
  *   result[0]     = sum(|p-l|*mask) / sum(mask)              (the masked-MAE loss over all horizons)
  *   result[1 + k] = the same restricted to horizon k          (MAE@k+1)
  * pred (B, out, N, od) contiguous; y (B, y_steps >= out, N, y_feat), channels y_start .. y_start+od-1.
- * partials: caller-owned device scratch of 2*B*out floats; result: device, 1+out floats.  Two launches, fixed
- * summation order (no atomics): results are run-to-run identical. */
+ * partials: caller-owned device scratch of 2*B*out + 1 floats (the last one keeps sum(mask) for the gradient);
+ * result: device, 1+out floats.  Two launches, fixed summation order (no atomics): results are run-to-run identical. */
 int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
                       int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
                       float* partials, float* result, void* stream);
+
+/* Gradient of result[0] (the calculate_loss value) w.r.t. pred, for the training step: d_pred (B, out, N, od) =
+ * upstream[0] * std * sign(p - l) * mask / sum(mask), with `partials` as left by the matching matgcn_masked_mae call
+ * and `upstream` the device scalar autograd hands down (d loss / d loss = 1 for a plain loss.backward()). */
+int matgcn_masked_mae_grad(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
+                           int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
+                           const float* partials, const float* upstream, float* d_pred, void* stream);
 
 /* ---- training step: forward that keeps activations + backward -----------
  * Replaces torch autograd through MultiATGCN.forward as driven by TrafficStateExecutor._train_epoch

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
     "matgcn_masked_mae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
+    "matgcn_masked_mae_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
     "matgcn_train_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
     "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, C.c_size_t, _P,
                                        C.c_size_t, _P]),
@@ -112,8 +114,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 7:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 7" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != 8:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 8" % lib.matgcn_abi_version())
     _lib = lib
     return lib
 

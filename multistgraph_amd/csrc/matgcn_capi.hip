@@ -719,6 +719,20 @@ int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_step
   return launch_ok();
 }
 
+int matgcn_masked_mae_grad(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
+                           int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
+                           const float* partials, const float* upstream, float* d_pred, void* stream) {
+  if (!pred || !y || !partials || !upstream || !d_pred) return MATGCN_ERR_NULL;
+  if (batch < 1 || out_steps < 1 || out_steps > 64 || nodes < 1 || out_dim < 1 || y_steps < out_steps ||
+      y_start < 0 || y_start + out_dim > y_feat)
+    return MATGCN_ERR_BAD_ARG;
+  const size_t total = (size_t)batch * out_steps * nodes * out_dim;
+  hipLaunchKernelGGL(k_mae_grad, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, pred, y, out_steps, nodes,
+                     out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s, partials + 2 * (size_t)batch * out_steps,
+                     upstream, total, d_pred);
+  return launch_ok();
+}
+
 int matgcn_set_wavefront(int mode) {
   const int prev = g_wavefront_mode;
   g_wavefront_mode = mode != 0 ? 1 : 0;

@@ -639,5 +639,30 @@ __global__ __launch_bounds__(64) void k_mae_final(const float* __restrict__ part
     double ta = 0.0, tc = 0.0;
     for (int k = 0; k < outSteps; ++k) { ta += hAbs[k]; tc += hCnt[k]; }
     result[0] = tc > 0.0 ? (float)(ta / tc) : 0.f;      // all-masked: mask/mean(mask) is nan -> 0 (loss.py:24-27)
+    const_cast<float*>(partials)[2 * B * outSteps] = (float)tc;   // kept for the gradient (k_mae_grad)
   }
+}
+
+// gradient of result[0] w.r.t. pred: upstream * std * sign(p - l) * mask / sum(mask)   (torch: d|x| = sign(x), 0 at 0;
+// terms the forward replaced by 0 - NaN differences - get no gradient)
+__global__ __launch_bounds__(256) void k_mae_grad(const float* __restrict__ pred, const float* __restrict__ y,
+                                                  int outSteps, int N, int od, int ySteps, int yFeat, int yStart,
+                                                  float mean, float std, float nullVal, float minS,
+                                                  const float* __restrict__ count, const float* __restrict__ upstream,
+                                                  size_t total, float* __restrict__ dpred) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = idx % od;
+  const int n = (idx / od) % N;
+  const int o = (idx / ((size_t)od * N)) % outSteps;
+  const size_t b = idx / ((size_t)od * N * outSteps);
+  float l = y[((b * ySteps + o) * N + n) * yFeat + yStart + c] * std + mean;
+  const float p = pred[idx] * std + mean;
+  if (fabsf(l) < minS) l = 0.f;
+  const bool nanMask = nullVal != nullVal;
+  const float m = nanMask ? (l == l ? 1.f : 0.f) : (l != nullVal ? 1.f : 0.f);
+  const float d = p - l;
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);      // NaN compares false both ways: 0
+  const float cnt = count[0];
+  dpred[idx] = cnt > 0.f ? upstream[0] * std * sgn * m / cnt : 0.f;
 }

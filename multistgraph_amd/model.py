@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import graph_prep
-from .ops import HotPath, PathSpec, diagonal_mask, masked_mae_device, spec_from_config
+from .ops import HotPath, PathSpec, diagonal_mask, masked_mae_device, masked_mae_loss, spec_from_config
 
 try:  # inside a LibCity checkout: subclass the real plugin base so isinstance checks hold
     from libcity.model.abstract_traffic_state_model import AbstractTrafficStateModel  # type: ignore
@@ -297,7 +297,9 @@ class MultiATGCN(AbstractTrafficStateModel):
         y_true = batch["y"]
         y_predicted = self.predict(batch)
         affine = self._affine_scaler()
-        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32 and not y_predicted.requires_grad:
+        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32 and y_predicted.requires_grad:
+            return masked_mae_loss(y_predicted, y_true, self.start_dim, affine[0], affine[1], null_val=0.0)
+        if affine is not None and y_true.is_cuda and y_true.dtype == torch.float32:
             return masked_mae_device(y_predicted, y_true, self.start_dim, affine[0], affine[1], null_val=0.0)[0]
         y_true = self._scaler.inverse_transform(y_true[..., self.start_dim:self.end_dim])
         y_predicted = self._scaler.inverse_transform(y_predicted)

@@ -152,24 +152,59 @@ def debug_gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, desc, alpha=1.
                                      C.c_float(alpha), C.c_float(beta), stream), "matgcn_debug_gemm")
 
 
-def masked_mae_device(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
-                      null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
-    """(1 + out,) tensor [masked-MAE over all horizons, MAE@1 .. MAE@out] computed on the device by
-    matgcn_masked_mae (de-scale + mask + reduce; reference loss.py:17-29, traffic_state_evaluator.py:87-104)."""
+def _mae_call(pred, y, y_start, mean, std, null_val, min_s):
     lib = _lib.load()
     pred = _check_tensor(pred, "pred")
     y = _check_tensor(y, "y")
     b, out, n, od = pred.shape
     if y.dim() != 4 or y.shape[0] != b or y.shape[2] != n:
         raise _lib.MatgcnError("y has shape %s, incompatible with pred %s" % (tuple(y.shape), tuple(pred.shape)))
-    partials = torch.empty(2 * b * out, dtype=torch.float32, device=pred.device)
+    partials = torch.empty(2 * b * out + 1, dtype=torch.float32, device=pred.device)
     result = torch.empty(1 + out, dtype=torch.float32, device=pred.device)
     stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
     _lib.check(lib.matgcn_masked_mae(C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), b, out, n, od,
                                      int(y.shape[1]), int(y.shape[3]), int(y_start), float(mean), float(std),
                                      float(null_val), float(min_s), C.c_void_p(partials.data_ptr()),
                                      C.c_void_p(result.data_ptr()), stream), "matgcn_masked_mae")
-    return result
+    return pred, y, partials, result
+
+
+def masked_mae_device(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
+                      null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
+    """(1 + out,) tensor [masked-MAE over all horizons, MAE@1 .. MAE@out] computed on the device by
+    matgcn_masked_mae (de-scale + mask + reduce; reference loss.py:17-29, traffic_state_evaluator.py:87-104)."""
+    return _mae_call(pred, y, y_start, mean, std, null_val, min_s)[3]
+
+
+class _MaskedMAE(torch.autograd.Function):
+    """calculate_loss on the device with its gradient (matgcn_masked_mae / matgcn_masked_mae_grad)."""
+
+    @staticmethod
+    def forward(ctx, pred, y, y_start, mean, std, null_val, min_s):
+        pred_c, y_c, partials, result = _mae_call(pred.detach(), y, y_start, mean, std, null_val, min_s)
+        ctx.save_for_backward(pred_c, y_c, partials)
+        ctx.args = (int(y_start), float(mean), float(std), float(null_val), float(min_s))
+        return result[0].clone()
+
+    @staticmethod
+    def backward(ctx, upstream):
+        pred, y, partials = ctx.saved_tensors
+        y_start, mean, std, null_val, min_s = ctx.args
+        b, out, n, od = pred.shape
+        d_pred = torch.empty_like(pred)
+        up = upstream.detach().to(torch.float32).reshape(1).contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
+        _lib.check(_lib.load().matgcn_masked_mae_grad(
+            C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), b, out, n, od, int(y.shape[1]), int(y.shape[3]),
+            y_start, mean, std, null_val, min_s, C.c_void_p(partials.data_ptr()), C.c_void_p(up.data_ptr()),
+            C.c_void_p(d_pred.data_ptr()), stream), "matgcn_masked_mae_grad")
+        return d_pred, None, None, None, None, None, None
+
+
+def masked_mae_loss(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
+                    null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
+    """The calculate_loss scalar with autograd support: the device reduction forward, matgcn_masked_mae_grad backward."""
+    return _MaskedMAE.apply(pred, y, y_start, mean, std, null_val, min_s)
 
 
 class HotPath:

@@ -90,3 +90,28 @@ def test_fused_loss_and_horizon_mae_with_a_real_scaler(lib_built):
     with torch.no_grad():
         l2 = m.calculate_loss(batch)
     assert torch.isfinite(l2)
+
+
+def test_fused_loss_gradient_matches_torch_autograd(lib_built):
+    """matgcn_masked_mae_grad vs autograd through the reference's torch arithmetic (loss.py:17-29) on the same
+    prediction: real scaler (mean 14.41, std 29.3), labels that de-scale to exactly 0 (masked out), a prediction that
+    equals its label (sign 0), and an upstream factor other than 1"""
+    from multistgraph_amd.model import masked_mae
+    from multistgraph_amd.ops import masked_mae_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    b, out, n = 5, 6, 33
+    mean, std = 14.41, 29.3
+    pred = torch.randn(b, out, n, 1, generator=g)
+    y = torch.randn(b, out + 2, n, 3, generator=g)
+    y[0, :, :4, 0] = -mean / std                 # de-scales to 0 -> masked
+    pred[1, 2, 7, 0] = y[1, 2, 7, 0]              # |p - l| = 0 exactly -> sign 0
+    p1 = pred.to(dev).requires_grad_(True)
+    loss = masked_mae_loss(p1, y.to(dev), 0, mean, std, null_val=0.0)
+    (3.0 * loss).backward()
+    p2 = pred.clone().requires_grad_(True)
+    want = masked_mae(p2 * std + mean, y[:, :out, :, 0:1].clone() * std + mean, 0.0)
+    (3.0 * want).backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * abs(float(want))
+    assert max_norm_err(p1.grad.cpu().numpy(), p2.grad.numpy()) <= 1e-6
+    assert float(p1.grad[0, :, :4].abs().max()) == 0.0 and float(p1.grad[1, 2, 7, 0]) == 0.0
