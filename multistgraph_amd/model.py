@@ -159,8 +159,9 @@ class MultiATGCN(AbstractTrafficStateModel):
                                       "pass static=None (DESIGN.md, out of scope this round)")
         if self.input_window != 24:
             raise ValueError("the reference fuses 24-step heads (:373-393): input_window must be 24")
+        embed_dim_cfg = self.embed_dim_node
         if self.node_specific_off:
-            self.embed_dim_node = 1
+            self.embed_dim_node = 1     # what the encoder's AGCN pools see (:166); node_emb itself shrinks after init
 
         # ---- one-off host graph prep (:238-283) -> first-order static supports (fp32, host)
         mats = graph_prep.build_static_supports(data_feature.get("adj_mx"), data_feature.get("coordinate"),
@@ -172,7 +173,11 @@ class MultiATGCN(AbstractTrafficStateModel):
         # ---- parameters, registered in the reference's order with the reference's names (:285-344)
         n = self.num_nodes
         rank = min(n, self.embed_dim_adj)  # torch.svd(adj)[..][:, :embed_dim_adj] (:299-304)
-        self.node_emb = nn.Parameter(torch.empty(n, self.embed_dim_node))
+        # Every step below that consumes torch's global RNG does so in the reference's order, so that the same
+        # torch.manual_seed gives bit-identical initial weights: the randn of (:296) - drawn at the CONFIG width even
+        # under node_specific_off (the reference shrinks its own embed_dim_node only at :351) -, the nn.Linear /
+        # Conv2d constructors, then _init_parameters over parameters() in registration order.
+        self.node_emb = nn.Parameter(torch.randn(n, embed_dim_cfg))
         self.node_vec1 = nn.Parameter(torch.empty(n, rank))
         self.node_vec2 = nn.Parameter(torch.empty(rank, n))
         self.spec: PathSpec = spec_from_config(config, data_feature, n, rank,
@@ -186,8 +191,11 @@ class MultiATGCN(AbstractTrafficStateModel):
         self.weight_tsg = nn.Parameter(torch.empty(self.len_ts))
         self.encoder = _EncoderParams(self.num_layers, self.input_window, self.feature_final, self.hidden_dim,
                                       self.spec.k_total, self.embed_dim_node, self.gcn_off)
-        self.end_conv = nn.Conv2d(1 if self.fnn_off else self.input_window, self.output_window * self.output_dim,
-                                  kernel_size=(1, self.hidden_dim), bias=True)   # (:340-344)
+        self.end_conv = nn.Conv2d(self.input_window, self.output_window * self.output_dim,
+                                  kernel_size=(1, self.hidden_dim), bias=True)   # (:340-341)
+        if self.fnn_off:   # the reference builds the full head first, then replaces it (:342-344): two sets of draws
+            self.end_conv = nn.Conv2d(1, self.output_window * self.output_dim, kernel_size=(1, self.hidden_dim),
+                                      bias=True)
         self._logger = getLogger()
         self._scaler = data_feature.get("scaler")
         self._init_parameters()

@@ -145,3 +145,47 @@ def test_training_entry_points_check_their_arguments(lib_built):
     assert lib.matgcn_forward_train(C.byref(d), C.byref(p), None, None, None, None, None, 0, None, 0, None) == -1
     assert lib.matgcn_backward(C.byref(d), C.byref(p), None, None, None, None, C.byref(p), None, 0, None, 0, None) == -1
     assert lib.matgcn_debug_gemm(None, None, None, None, 1.0, 0.0, None) == -1
+
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _reference_model_class():
+    """The reference's own MultiATGCN class - build container only (the reference never travels)."""
+    import sys
+    if not os.path.isdir(os.path.join(REFERENCE_ROOT, "libcity")):
+        pytest.skip("reference checkout not present (GPU box): same-seed check runs in the build container")
+    sys.dont_write_bytecode = True      # the reference tree is read-only
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.append(REFERENCE_ROOT)
+    import libcity.model.traffic_flow_prediction.MultiATGCN  # noqa: F401
+    return sys.modules["libcity.model.traffic_flow_prediction.MultiATGCN"].MultiATGCN
+
+
+@pytest.mark.parametrize("name,extra", [
+    ("tiny_multi_uni_c2", {}), ("tiny_od_non_c3", {}), ("tiny_multi_bid_c2", {}), ("tiny_multi_uni_dyn7", {}),
+    ("abl_gcnoff", {}), ("abl_fnnoff", {}), ("abl_nodeoff", {}), ("abl_gcnfnnoff", {}),
+    ("tiny_multi_uni_c2", {"cheb_order": 1}), ("tiny_od_non_c2", {"cheb_order": 1}),
+])
+def test_same_seed_gives_the_reference_initial_weights(name, extra):
+    """_init_parameters (MultiATGCN.py:356-361) AND the RNG stream in front of it (:296 randn,
+    nn.Linear / Conv2d constructors, :291 pca_lowrank with static features) - the same torch.manual_seed must give
+    bit-identical state_dicts in the reference class and in the plugin."""
+    from multistgraph_amd import synthetic as syn
+    from multistgraph_amd.model import MultiATGCN
+    ref_cls = _reference_model_class()
+    c = Case(name)
+    cfg = dict(c.config())
+    static_dim = extra.get("static_dim", 0)
+    cfg.update({k: v for k, v in extra.items() if k != "static_dim"})
+    for seed in (0, 10):
+        dfs = [syn.make_data_feature(c.n, c.seed, ext_dim=c.feat - 1, static_dim=static_dim) for _ in range(2)]
+        torch.manual_seed(seed)
+        ref = ref_cls(dict(cfg), dfs[0])
+        torch.manual_seed(seed)
+        own = MultiATGCN(dict(cfg), dfs[1])
+        rs, os_ = ref.state_dict(), own.state_dict()
+        assert list(rs) == list(os_)
+        for k in rs:
+            assert rs[k].shape == os_[k].shape, k
+            assert torch.equal(rs[k], os_[k]), "%s differs for seed %d" % (k, seed)
