@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 8
+#define MATGCN_ABI_VERSION 9
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -63,7 +63,7 @@ typedef struct matgcn_dims {
   int32_t adj_rank;     /* r = node_vec1 columns (unidirection) */
   int32_t adp_mode;     /* MATGCN_ADP_* */
   int32_t n_static;     /* first-order static supports used by the stack (0..3), (:87-93) */
-  int32_t cheb_k;       /* cheb_order (>= 2) */
+  int32_t cheb_k;       /* cheb_order (>= 1; 1 = one weight broadcast over [I, S_1, S_2, ..], :65-70,94-108) */
   int32_t scale_by_g;   /* 1 iff adjtype == 'multi': stack *= softmax(weights_g) (:102-103) */
   int32_t n_heads;      /* temporal heads fused (2 if output_window < 6 else 4, :371-393) */
   int32_t n_ts;         /* len(weight_tsg) = len_ts (:328-332) */
@@ -118,6 +118,14 @@ int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes);
  * out[3] = number of DENSE non-identity slots Ks (diagonal supports are folded away, in stack order
  * otherwise).  Element S_k[n][m] of dense slot k is at prepared[out[0] + m*out[1] + k*Np + n]. */
 int matgcn_supports_layout(const matgcn_dims* dims, int64_t out[4]);
+
+/* Where the RECURRENT rows of a node-adaptive weight stream live inside `prepared` (for tests: what matgcn_prepare
+ * really wrote, including diagonal supports folded into the identity slot and softmax(weights_g)).
+ * part 0 = agru_cells[layer].gate (O = 128), 1 = .update (O = 64).  out[0] = float offset of node 0, out[1] = floats
+ * between nodes, out[2] = k-groups of 16 rows (= 4 * (1 + Ks)), out[3] = column tiles O/16.  Row kk = 64*slot + c is
+ * hidden channel c of node-GEMM slot `slot` (0 = identity, then the dense slots); W_n[kk][o] is at
+ *   out[0] + n*out[1] + (((kk/16)*out[3] + o/16)*64 + (o%16) + 16*((kk%16)/4))*4 + kk%4   (v_mfma_f32_16x16x4 B order). */
+int matgcn_weights_layout(const matgcn_dims* dims, int layer, int part, int64_t out[4]);
 
 /* ---- parameter-only work, once per parameter update ----------------------------------------
  * Replaces what AGCN.forward rebuilds on every call (MultiATGCN.py:78-105): the adaptive adjacency

@@ -11,6 +11,7 @@ import os
 
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
+ABI_VERSION = 9
 MAX_LAYERS = 4
 MAX_HEADS = 8
 MAX_EXT = 16
@@ -19,6 +20,8 @@ ADP_NONE, ADP_UNI, ADP_BI = 0, 1, 2
 ADP_CODES = {"none": ADP_NONE, "unidirection": ADP_UNI, "bidirection": ADP_BI}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmatgcn.so")
+if os.environ.get("MATGCN_LIB"):   # lab builds of the same library (build.build_variant); still HIP-only, still loud
+    LIB_PATH = os.path.abspath(os.environ["MATGCN_LIB"])
 
 
 class MatgcnError(RuntimeError):
@@ -62,6 +65,7 @@ _SIGNATURES = {
     "matgcn_prepared_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
     "matgcn_workspace_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
     "matgcn_supports_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_int64 * 4)]),
+    "matgcn_weights_layout": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.POINTER(C.c_int64 * 4)]),
     "matgcn_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_size_t, _P, C.c_size_t, _P]),
     "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
     "matgcn_forward_series": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.c_int64, _P,
@@ -114,8 +118,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.matgcn_abi_version() != 8:
-        raise MatgcnError("libmatgcn.so ABI version %d, binding expects 8" % lib.matgcn_abi_version())
+    if lib.matgcn_abi_version() != ABI_VERSION:
+        raise MatgcnError("libmatgcn.so ABI version %d, binding expects %d" % (lib.matgcn_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -46,6 +46,19 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     return LIB_PATH
 
 
+def build_variant(tag: str, extra_flags, verbose: bool = True) -> str:
+    """Lab builds (kernel parameter sweeps): lib/libmatgcn_<tag>.so next to the product library, selected at run time
+    with MATGCN_LIB=<path> (see _lib.py).  Never used by the product path."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    out = os.path.join(LIB_DIR, "libmatgcn_%s.so" % tag)
+    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           *extra_flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    if verbose:
+        print("[matgcn build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB_PATH)

@@ -60,29 +60,14 @@ struct Bwd {
   float* tr;
 };
 
-// original stack index k -> slot of the node GEMM (kept slots in order, diagonal ones share the identity slot)
-void slot_map(const Plan& P, const StackMap& map, int* slotOf) {
-  for (int k = 0; k < P.KtotOrig; ++k) slotOf[k] = 0;
-  for (int s2 = 0; s2 < map.nKeep; ++s2) slotOf[map.keepK[s2]] = s2;
-}
-
-StackMap build_stack_map(const Plan& P, const matgcn_dims* D, const matgcn_params* params) {
-  StackMap map;
-  memset(&map, 0, sizeof(map));
-  const int per = D->cheb_k - 1;
-  map.KtotOrig = P.KtotOrig; map.N = P.N;
-  map.keepK[0] = 0; map.nKeep = 1;
-  for (int fd = 0; fd < P.nDenseFirst; ++fd)
-    for (int j = 0; j < per; ++j) map.keepK[map.nKeep++] = 1 + P.denseFirst[fd] * per + j;
-  const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
-  for (int q = 0; q < P.nDiagFirst; ++q)
-    for (int j = 0; j < per; ++j) {
-      map.diagK[map.nDiag] = 1 + P.diagFirst[q] * per + j;
-      map.diagOrder[map.nDiag] = j + 1;
-      map.diagSrc[map.nDiag] = params->static_supports + (size_t)(P.diagFirst[q] - adp) * P.N * P.N;
-      ++map.nDiag;
-    }
-  return map;
+// the stack entries whose weights come out of the pools: kept slots first, then the folded diagonal ones (which share
+// the identity slot); with cheb_order = 1 several entries alias pool index 0 (StackMap)
+StackEntries stack_entries(const StackMap& map) {
+  StackEntries e;
+  memset(&e, 0, sizeof(e));
+  for (int s2 = 0; s2 < map.nKeep; ++s2) { e.pool[e.n] = map.keepK[s2]; e.slot[e.n] = s2; e.diag[e.n] = -1; ++e.n; }
+  for (int q = 0; q < map.nDiag; ++q) { e.pool[e.n] = map.diagK[q]; e.slot[e.n] = 0; e.diag[e.n] = q; ++e.n; }
+  return e;
 }
 
 // dst[rows][m][i] = sum_kk StP[kk][m] * src[rows][slot 1..][kk][i]: the transposed graph mix of the dense slots of a
@@ -200,7 +185,7 @@ struct Pass {
   int hT, tOff;              // fnn_off: the head sees the last step only (MultiATGCN.py:412)
   int fusedLds;
   StackMap map;
-  int slotOf[MATGCN_MAX_STACK];
+  StackEntries ent;
 };
 
 // per-layer views of the scratch (index l & 1: the weight gradients of layer l run on the second stream while the
@@ -226,7 +211,7 @@ struct LayerBufs {
   [[maybe_unused]] const long slab = (long)B * Np * H; [[maybe_unused]] const int rowsTB = T * B;                   \
   [[maybe_unused]] const bool twoStreams = (q).twoStreams, adp = (q).adp;                                           \
   [[maybe_unused]] const int hT = (q).hT, tOff = (q).tOff, fusedLds = (q).fusedLds;                                 \
-  [[maybe_unused]] const StackMap& map = (q).map; [[maybe_unused]] const int* slotOf = (q).slotOf;                  \
+  [[maybe_unused]] const StackMap& map = (q).map; [[maybe_unused]] const StackEntries& ent = (q).ent;               \
   [[maybe_unused]] float* dT = tr + R.oDT
 
 #define LAYER_LOCALS(L)                                                                                            \
@@ -666,23 +651,27 @@ int bwd_pools(Pass& pass) {
       const float* wg = D->scale_by_g ? ap.weights_g : nullptr;
       const float* dWp = tr + R.oDWp[l][part];
       const float* dBias = tr + R.oDBias[l][part];
-      hipLaunchKernelGGL(k_scaled_emb, dim3(blocks_for((size_t)N * P.d), (unsigned)Kt), dim3(256), 0, s, prm->node_emb,
-                         wg, map, P.d, EK, FK);
+      hipLaunchKernelGGL(k_scaled_emb, dim3(blocks_for((size_t)N * P.d), (unsigned)ent.n), dim3(256), 0, s,
+                         prm->node_emb, wg, map, ent, P.d, EK, FK);
       CHECK_LAUNCH();
-      RETURN_IF(zero_async(TmpK, (long)Kt * N * P.d, s));
+      RETURN_IF(zero_async(TmpK, (long)ent.n * N * P.d, s));
       RETURN_IF(zero_async(dgain, 64, s));
-      for (int k = 0; k < Kt; ++k) {
-        const float* src = dWp + (size_t)slotOf[k] * IO;
-        GemmArgs q = gemm_args(EK + (size_t)k * N * P.d, src, ag.weights_pool + (size_t)k * IO, P.d, (int)IO, N);
+      bool written[MATGCN_MAX_STACK] = {false};
+      for (int e2 = 0; e2 < ent.n; ++e2) {
+        const int k = ent.pool[e2];
+        const float* src = dWp + (size_t)ent.slot[e2] * IO;
+        GemmArgs q = gemm_args(EK + (size_t)e2 * N * P.d, src, ag.weights_pool + (size_t)k * IO, P.d, (int)IO, N);
         q.sAm = 1; q.sAk = P.d; q.sBk = (long)S * IO; q.sBn = 1; q.sCm = (long)Kt * IO; q.sCn = 1;
+        q.beta = written[k] ? 1.f : 0.f;   // entries that alias one pool index (cheb_order = 1) add up
+        written[k] = true;
         RETURN_IF(gemm(q, 1, s, BG_POOL));
-        GemmArgs e = gemm_args(src, ap.weights_pool + (size_t)k * IO, TmpK + (size_t)k * N * P.d, N, P.d, (int)IO);
+        GemmArgs e = gemm_args(src, ap.weights_pool + (size_t)k * IO, TmpK + (size_t)e2 * N * P.d, N, P.d, (int)IO);
         e.sAm = (long)S * IO; e.sAk = 1; e.sBk = 1; e.sBn = (long)Kt * IO; e.sCm = P.d; e.sCn = 1;
         e.mode = 1; e.split = 32;
         RETURN_IF(gemm(e, 1, s, BG_POOL));
       }
-      hipLaunchKernelGGL(k_emb_grad, dim3(blocks_for((size_t)N * P.d), (unsigned)Kt), dim3(256), 0, s, TmpK, FK,
-                         prm->node_emb, wg, Kt, N, P.d, g->node_emb, dgain);
+      hipLaunchKernelGGL(k_emb_grad, dim3(blocks_for((size_t)N * P.d), (unsigned)ent.n), dim3(256), 0, s, TmpK, FK,
+                         prm->node_emb, wg, Kt, ent, N, P.d, g->node_emb, dgain);
       CHECK_LAUNCH();
       if (D->scale_by_g) {
         hipLaunchKernelGGL(k_softmax_bwd_small, dim3(1), dim3(64), 0, s, ap.weights_g, dgain, Kt, ag.weights_g);
@@ -763,7 +752,7 @@ int backward_impl(Bwd& b, const float* dOut) {
   q.adp = b.c.D->adp_mode != MATGCN_ADP_NONE && !P.gcnOff;
   q.hT = P.headT; q.tOff = P.T - P.headT;
   q.map = build_stack_map(P, b.c.D, b.c.prm);
-  slot_map(P, q.map, q.slotOf);
+  q.ent = stack_entries(q.map);
   // the weight gradients of a layer (big GEMMs) run on a library stream while the caller's stream already walks the
   // chain of the layer below (small dependent launches); matgcn_set_wavefront(0) keeps everything on one stream
   RETURN_IF(wavefront_ready());

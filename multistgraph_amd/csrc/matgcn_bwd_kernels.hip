@@ -209,33 +209,33 @@ __global__ __launch_bounds__(256) void k_prep_plain(PlainPrep a) {
   a.out[(size_t)n * per + idx] = acc;
 }
 
-// EK[k][n][d] = g_k * f_k[n] * E[n][d], f_k = 1 for kept slots, the Chebyshev value of the diagonal otherwise;
-// FK[k][n] = f_k[n]  (left operands of the pool-gradient GEMMs)
+// EK[e][n][d] = g_k * f_e[n] * E[n][d] for stack entry e with pool index k: f = 1 for kept slots, the Chebyshev value of
+// the diagonal for folded ones;  FK[e][n] = f_e[n]  (left operands of the pool-gradient GEMMs)
 __global__ __launch_bounds__(256) void k_scaled_emb(const float* __restrict__ E, const float* __restrict__ wg,
-                                                    StackMap map, int d, float* __restrict__ EK,
+                                                    StackMap map, StackEntries ent, int d, float* __restrict__ EK,
                                                     float* __restrict__ FK) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int k = blockIdx.y;
+  const int e = blockIdx.y;
   if (idx >= map.N * d) return;
   const int n = idx / d;
-  float f = 1.f;
-  for (int q = 0; q < map.nDiag; ++q)
-    if (map.diagK[q] == k) f = cheb_scalar(map.diagSrc[q][(size_t)n * (map.N + 1)], map.diagOrder[q]);
-  EK[(size_t)k * map.N * d + idx] = stack_gain(wg, map.KtotOrig, k) * f * E[idx];
-  if (idx % d == 0) FK[(size_t)k * map.N + n] = f;
+  const int q = ent.diag[e];
+  const float f = q >= 0 ? cheb_scalar(map.diagSrc[q][(size_t)n * (map.N + 1)], map.diagOrder[q]) : 1.f;
+  EK[(size_t)e * map.N * d + idx] = stack_gain(wg, map.KtotOrig, ent.pool[e]) * f * E[idx];
+  if (idx % d == 0) FK[(size_t)e * map.N + n] = f;
 }
 
-// dE[n][d] += sum_k g_k f_k[n] TmpK[k][n][d];   dgain[k] += sum_{n,d} f_k[n] E[n][d] TmpK[k][n][d]
+// dE[n][d] += sum_e g_k(e) f_e[n] TmpK[e][n][d];   dgain[k(e)] += sum_{n,d} f_e[n] E[n][d] TmpK[e][n][d]
 __global__ __launch_bounds__(256) void k_emb_grad(const float* __restrict__ TmpK, const float* __restrict__ FK,
                                                   const float* __restrict__ E, const float* __restrict__ wg, int Kt,
-                                                  int N, int d, float* __restrict__ dE, float* __restrict__ dgain) {
+                                                  StackEntries ent, int N, int d, float* __restrict__ dE,
+                                                  float* __restrict__ dgain) {
   __shared__ float red[256];
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int k = blockIdx.y;
+  const int e = blockIdx.y, k = ent.pool[e];
   float part = 0.f;
   if (idx < N * d) {
     const int n = idx / d;
-    const float f = FK[(size_t)k * N + n], v = TmpK[(size_t)k * N * d + idx];
+    const float f = FK[(size_t)e * N + n], v = TmpK[(size_t)e * N * d + idx];
     if (dE) unsafeAtomicAdd(&dE[idx], stack_gain(wg, Kt, k) * f * v);
     part = f * E[idx] * v;
   }

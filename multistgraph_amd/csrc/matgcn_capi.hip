@@ -30,6 +30,7 @@ inline long rup(long v, long m) { return (v + m - 1) / m * m; }
 struct Plan {
   int B, N, Np, T, L, C0, Ks, Ktot, nFirst, Mp, Kx, d, CH, NTc, od, Tc;   // Ks/Ktot: DENSE slots (+ identity)
   int per, KtotOrig, nDenseFirst;
+  int sumDense;               // cheb_order = 1: the dense first-order supports share one weight and are summed into one slot
   int gcnOff, headT;          // ablations: dense GRU cells instead of graph cells; head over the last step only
   int denseFirst[4];          // first-order supports that are mixed (index into [adaptive?, statics...])
   int diagFirst[4], nDiagFirst;
@@ -41,7 +42,8 @@ struct Plan {
   long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
   long wxStride;
   int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], nGx[MATGCN_MAX_LAYERS];
-  int nodeLds;                // dynamic LDS bytes of the node kernels
+  int nodeLds;                // dynamic LDS bytes of k_px16 (whole 64-row tile: x slots + mixed slots)
+  int RB;                     // 64-row blocks of the batch: the unit of the fragment-ordered PX / R blocks
   long preparedFloats;
   // workspace offsets (floats); state buffers are per layer so that layers can run concurrently
   long oX0p, oX0m, oMX0, oXA0;
@@ -59,7 +61,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   if (D->out_dim < 1 || D->out_channels < 1 || D->out_channels % D->out_dim) return MATGCN_ERR_BAD_ARG;
   if (D->out_channels > 64) return MATGCN_ERR_UNSUPPORTED;
   if (D->feat_in < D->out_dim || D->feat_in - D->out_dim > MATGCN_MAX_EXT || D->feat_in > 64) return MATGCN_ERR_BAD_ARG;
-  if (D->embed_dim < 1 || D->cheb_k < 2 || D->n_static < 0 || D->n_static > 3) return MATGCN_ERR_BAD_ARG;
+  if (D->embed_dim < 1 || D->cheb_k < 1 || D->n_static < 0 || D->n_static > 3) return MATGCN_ERR_BAD_ARG;
   if (D->adp_mode < 0 || D->adp_mode > 2) return MATGCN_ERR_BAD_ARG;
   if (D->adp_mode == MATGCN_ADP_UNI && (D->adj_rank < 1 || D->adj_rank > 64)) return MATGCN_ERR_BAD_ARG;
   if (D->adp_mode == MATGCN_ADP_BI && D->embed_dim > 64) return MATGCN_ERR_BAD_ARG;
@@ -75,13 +77,18 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   P->d = D->embed_dim; P->CH = D->out_channels; P->od = D->out_dim;
   P->Np = (int)rup(P->N, 16);
   P->NpC = (int)rup(P->N, 64);
+  // the write-through row stores of the node kernels (store_wt16) address a step's state slab [B][Np][64] and the
+  // reset-gate block [N][B][64] with 32-bit byte offsets: keep a slab below 2^29 floats (B * Np < 8.4 M)
+  if ((long)P->B * P->Np * H >= (1L << 29)) return MATGCN_ERR_UNSUPPORTED;
   const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
   P->gcnOff = D->gcn_off ? 1 : 0;
   P->headT = D->fnn_off ? 1 : P->T;
   P->nFirst = adp + D->n_static;
   if (P->nFirst < 1 && !P->gcnOff) return MATGCN_ERR_BAD_ARG;
-  P->per = D->cheb_k - 1;
-  P->KtotOrig = 1 + P->nFirst * P->per;
+  // cheb_order = 1: one weight entry broadcast over [I, S_1, S_2, ..] (MultiATGCN.py:65-70,94-108; StackMap)
+  P->sumDense = D->cheb_k == 1 ? 1 : 0;
+  P->per = P->sumDense ? 1 : D->cheb_k - 1;
+  P->KtotOrig = P->sumDense ? 1 : 1 + P->nFirst * P->per;
   if (P->KtotOrig > MATGCN_MAX_STACK) return MATGCN_ERR_UNSUPPORTED;
   if (D->diag_static_mask < 0 || D->diag_static_mask >= (1 << D->n_static)) return MATGCN_ERR_BAD_ARG;
   for (int f = 0; f < P->nFirst; ++f) {
@@ -89,7 +96,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     if (diag) P->diagFirst[P->nDiagFirst++] = f;
     else P->denseFirst[P->nDenseFirst++] = f;
   }
-  P->Ks = P->nDenseFirst * P->per;
+  P->Ks = P->sumDense ? (P->nDenseFirst > 0 ? 1 : 0) : P->nDenseFirst * P->per;
   if (P->gcnOff) { P->Ks = 0; P->nDenseFirst = 0; P->nDiagFirst = 0; }
   P->Ktot = P->Ks + 1;
   P->Mp = (int)rup((long)P->Ks * P->Np, 64);
@@ -120,7 +127,8 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   }
   P->oHead = take((long)P->headT * H * 32 * P->NTc);
   P->preparedFloats = o;
-  P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 4 ? P->Ks : 4)) * (int)sizeof(float);
+  P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 1 ? P->Ks : 1)) * (int)sizeof(float);
+  P->RB = (P->B + 63) / 64;
   // workspace
   o = 0;
   const long rowsBT = (long)P->B * P->T;
@@ -132,11 +140,11 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oHx[l] = take((long)P->B * P->Np * H);
     P->oZHx[l] = take((long)P->B * P->Np * H);
     P->oG[l] = take((long)P->N * P->B * P->Ks * H);
-    P->oR[l] = take((long)P->N * P->B * H);
+    P->oR[l] = take((long)P->N * P->RB * NODE_R_BLOCK);
     P->oSeq[l] = take(rowsBT * P->Np * H);
     if (l > 0 && !P->gcnOff) {
       P->oGX[l] = take((long)P->T * P->N * P->B * P->Ks * H);   // every chunk keeps its own block [N][nt*B][Ks][64]
-      P->oPX[l] = take((long)P->T * P->N * P->B * 192);
+      P->oPX[l] = take((long)P->T * P->N * P->RB * NODE_PX_BLOCK);
     }
   }
   P->workspaceFloats = o;
@@ -209,8 +217,9 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
   R->oMixN = take((long)P.T * P.B * P.Np * P.C0);
   R->oDT = take((long)P.per * P.N * P.N); R->oDL = take((long)P.N * P.N);   // dT: one (N,N) per Chebyshev order
-  R->oEK = take((long)P.KtotOrig * P.N * P.d); R->oFK = take((long)P.KtotOrig * P.N);
-  R->oTmpK = take((long)P.KtotOrig * P.N * P.d); R->oDGain = take(64);
+  const long nEnt = P.KtotOrig + 4;   // stack entries the pool gradients walk (cheb_order = 1: up to 2 + 3 on one pool index)
+  R->oEK = take(nEnt * P.N * P.d); R->oFK = take(nEnt * P.N);
+  R->oTmpK = take(nEnt * P.N * P.d); R->oDGain = take(64);
   R->oDOutRows = take((long)P.B * P.Np * P.CH);
   R->oStP = take((long)P.Ks * P.Np * P.NpC);
   R->floats = o;
@@ -330,6 +339,29 @@ int mix_rows(const Plan& P, const float* St, const float* X, int rows, float* G,
                     (long)(P.N - 1) * sN + (long)rows * P.Ks * H);
 }
 
+// the stack entries the kernels see (StackMap): kept slots (identity + dense) and folded diagonal ones
+StackMap build_stack_map(const Plan& P, const matgcn_dims* D, const matgcn_params* params) {
+  StackMap map;
+  memset(&map, 0, sizeof(map));
+  map.KtotOrig = P.KtotOrig; map.N = P.N;
+  map.keepK[0] = 0; map.nKeep = 1;
+  const int adp = D->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
+  if (P.sumDense) {
+    if (P.nDenseFirst > 0) map.keepK[map.nKeep++] = 0;   // the summed dense slot reads the one weight entry
+  } else {
+    for (int fd = 0; fd < P.nDenseFirst; ++fd)
+      for (int j = 0; j < P.per; ++j) map.keepK[map.nKeep++] = 1 + P.denseFirst[fd] * P.per + j;
+  }
+  for (int q = 0; q < P.nDiagFirst; ++q)
+    for (int j = 0; j < P.per; ++j) {
+      map.diagK[map.nDiag] = P.sumDense ? 0 : 1 + P.diagFirst[q] * P.per + j;
+      map.diagOrder[map.nDiag] = j + 1;
+      map.diagSrc[map.nDiag] = params->static_supports + (size_t)(P.diagFirst[q] - adp) * P.N * P.N;
+      ++map.nDiag;
+    }
+  return map;
+}
+
 struct Ctx {
   Plan P;
   const matgcn_dims* D;
@@ -341,18 +373,21 @@ struct Ctx {
   TrainPlan R;
 };
 
-// dynamic LDS above 64 KB must be opted into once per kernel
+// dynamic LDS: k_gate16 48 KB (state chunk + two ping-pong chunks), k_update16 64 KB (+ the x_t tile of the residual
+// cell), k_px16 the whole tile; sizes above 64 KB must be opted into once per kernel
+constexpr int GATE_LDS = 3 * 4096 * (int)sizeof(float);
+constexpr int UPDATE_LDS = 4 * 4096 * (int)sizeof(float);
 int node_kernels_ready(int ldsBytes) {
   static int ready = 0;
   if (ready >= ldsBytes) return MATGCN_OK;
   const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -400,10 +435,10 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
   }
   Px16Args a;
   a.x = xin; a.g = GX; a.w = c.prep + P.oWx[l]; a.bias = c.prep + P.oBx[l];
-  a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.B * 192;
-  a.rows = rows; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks; a.B = P.B;
+  a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.RB * NODE_PX_BLOCK;
+  a.steps = nt; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks; a.B = P.B;
   ProfScope prof(MATGCN_PROF_PX, s);
-  hipLaunchKernelGGL(k_px16, dim3((unsigned)(rup(P.N, 8) * ((rows + 63) / 64))), dim3(512), P.nodeLds, s, a);
+  hipLaunchKernelGGL(k_px16, dim3((unsigned)(rup(P.N, 8) * nt * P.RB)), dim3(512), P.nodeLds, s, a);
   return launch_ok();
 }
 
@@ -456,8 +491,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   memset(&a, 0, sizeof(a));
   a.g = G; a.gNodeStride = phase == 1 ? gNodeStride : 0; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
-  else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.B * 192;
-  const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
+  else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.RB * NODE_PX_BLOCK;
+  const dim3 grid((unsigned)P.N, (unsigned)P.RB);
   const bool save = c.train != nullptr && res != nullptr;
   if (save) {
     const size_t at = (size_t)t * P.B * P.Np * H;
@@ -467,8 +502,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   if (phase == 1) {
     a.s = Hx; a.w = c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    if (save) hipLaunchKernelGGL(k_gate16<true>, grid, dim3(512), P.nodeLds, s, a);
-    else hipLaunchKernelGGL(k_gate16<false>, grid, dim3(512), P.nodeLds, s, a);
+    if (save) hipLaunchKernelGGL(k_gate16<true>, grid, dim3(512), GATE_LDS, s, a);
+    else hipLaunchKernelGGL(k_gate16<false>, grid, dim3(512), GATE_LDS, s, a);
     return launch_ok();
   }
   a.s = ZHx; a.w = c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
@@ -477,10 +512,10 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    if (save) hipLaunchKernelGGL((k_update16<1, true>), grid, dim3(512), P.nodeLds, s, a);
-    else hipLaunchKernelGGL((k_update16<1, false>), grid, dim3(512), P.nodeLds, s, a);
+    if (save) hipLaunchKernelGGL((k_update16<1, true>), grid, dim3(512), UPDATE_LDS, s, a);
+    else hipLaunchKernelGGL((k_update16<1, false>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
-    hipLaunchKernelGGL((k_update16<0, false>), grid, dim3(512), P.nodeLds, s, a);
+    hipLaunchKernelGGL((k_update16<0, false>), grid, dim3(512), UPDATE_LDS, s, a);
   }
   return launch_ok();
 }
@@ -505,7 +540,7 @@ int res_step(const Ctx& c, int l, const float* xt, long xRowStride) {
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, &a);
   ProfScope prof(MATGCN_PROF_RES, c.s);
-  hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)((P.B + 63) / 64)), dim3(512), P.nodeLds, c.s, a);
+  hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)P.RB), dim3(512), UPDATE_LDS, c.s, a);
   return launch_ok();
 }
 
@@ -561,9 +596,9 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
           if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
             const size_t at = (size_t)t * P.B * P.Np * H;
             a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
-            hipLaunchKernelGGL((k_update16<2, true>), grid, dim3(512), P.nodeLds, cs, a);
+            hipLaunchKernelGGL((k_update16<2, true>), grid, dim3(512), UPDATE_LDS, cs, a);
           } else {
-            hipLaunchKernelGGL((k_update16<2, false>), grid, dim3(512), P.nodeLds, cs, a);
+            hipLaunchKernelGGL((k_update16<2, false>), grid, dim3(512), UPDATE_LDS, cs, a);
           }
         }
         CHECK_LAUNCH();
@@ -775,6 +810,18 @@ int matgcn_supports_layout(const matgcn_dims* dims, int64_t out[4]) {
   return MATGCN_OK;
 }
 
+int matgcn_weights_layout(const matgcn_dims* dims, int layer, int part, int64_t out[4]) {
+  if (!out) return MATGCN_ERR_NULL;
+  Plan P;
+  RETURN_IF(make_plan(dims, &P));
+  if (layer < 0 || layer >= P.L || part < 0 || part > 1 || P.gcnOff) return MATGCN_ERR_BAD_ARG;
+  const int O = part == 0 ? 128 : 64, nG = 4 * P.Ktot;
+  out[0] = part == 0 ? P.oWg[layer] : P.oWu[layer];
+  out[1] = (long)(nG + P.nGx[layer]) * 16 * O;
+  out[2] = nG; out[3] = O / 16;
+  return MATGCN_OK;
+}
+
 int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* prepared, size_t prepared_bytes,
                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared) return MATGCN_ERR_NULL;
@@ -790,7 +837,7 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   if (!params->end_conv_weight || !params->end_conv_bias) return MATGCN_ERR_NULL;
   float* prep = (float*)prepared;
   float* St = prep + P.oSt;
-  const int per = dims->cheb_k - 1;  // stack slots per first-order support
+  const int per = P.per;  // stack slots per first-order support
   if (P.Mp > 0) RETURN_IF(zero_async(St, (long)P.Np * P.Mp, c.s));
   const bool cheb = dims->cheb_k > 2 && P.nDenseFirst > 0;
   float* plainA = cheb ? prep + P.oPlainA : nullptr;  // T_{k-1}
@@ -804,9 +851,10 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   const dim3 tgrid((unsigned)((P.N + 31) / 32), (unsigned)((P.N + 31) / 32));
   for (int fd = 0; fd < P.nDenseFirst; ++fd) {   // diagonal supports are folded into the weights instead
     const int f = P.denseFirst[fd];
-    const int slot0 = fd * per;
+    const int slot0 = P.sumDense ? 0 : fd * per;   // cheb_order = 1: every dense support adds into the one slot
     const int col0 = slot0 * P.Np;
-    const bool adaptive = (dims->adp_mode != MATGCN_ADP_NONE) && f == 0;
+    const int accumulate = P.sumDense && fd > 0 ? 1 : 0;
+    const bool adaptive = (dims->adp_mode != MATGCN_ADP_NONE) && f == 0;   // always the first dense support
     if (adaptive) {
       const bool bi = dims->adp_mode == MATGCN_ADP_BI;
       hipLaunchKernelGGL(k_adaptive_adj, dim3(P.N), dim3(256), 0, c.s, bi ? params->node_emb : params->node_vec1,
@@ -815,7 +863,8 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     } else {
       const int sidx = f - (dims->adp_mode != MATGCN_ADP_NONE ? 1 : 0);
       hipLaunchKernelGGL(k_static_transpose, tgrid, dim3(256), 0, c.s,
-                         params->static_supports + (size_t)sidx * P.N * P.N, P.N, St, P.Mp, col0, plainA, P.NpC);
+                         params->static_supports + (size_t)sidx * P.N * P.N, P.N, St, P.Mp, col0, plainA, P.NpC,
+                         accumulate);
     }
     CHECK_LAUNCH();
     // Chebyshev orders 2..cheb_k-1 of this support: T_k = 2 S T_{k-1} - T_{k-2} (T_0 = I, T_1 = S).
@@ -845,22 +894,7 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     HIP_OK(hipStreamWaitEvent(pool[2], W.fork, 0));
   }
   int piece = 0;
-  StackMap map;
-  memset(&map, 0, sizeof(map));
-  map.KtotOrig = P.KtotOrig; map.N = P.N;
-  map.keepK[0] = 0; map.nKeep = 1;
-  for (int fd = 0; fd < P.nDenseFirst; ++fd)
-    for (int j = 0; j < per; ++j) map.keepK[map.nKeep++] = 1 + P.denseFirst[fd] * per + j;
-  {
-    const int adp = dims->adp_mode != MATGCN_ADP_NONE ? 1 : 0;
-    for (int q = 0; q < P.nDiagFirst; ++q)
-      for (int j = 0; j < per; ++j) {
-        map.diagK[map.nDiag] = 1 + P.diagFirst[q] * per + j;
-        map.diagOrder[map.nDiag] = j + 1;
-        map.diagSrc[map.nDiag] = params->static_supports + (size_t)(P.diagFirst[q] - adp) * P.N * P.N;
-        ++map.nDiag;
-      }
-  }
+  const StackMap map = build_stack_map(P, dims, params);
   const unsigned nodeGroups = (unsigned)((P.N + PREP_NB - 1) / PREP_NB);
   for (int l = 0; l < P.L; ++l) {
     const int I = P.Cl[l] + H;

@@ -10,15 +10,29 @@
 // kernels see.  Supports that are diagonal matrices (e.g. the similarity Laplacian -I when there are no static
 // features, MultiATGCN.py:244-250) need no graph mix at all: S x = diag(s) x, so their weight rows are folded into
 // the identity slot, scaled per node by the Chebyshev value t_order(s_n), and they disappear from the stack.
+//
+// cheb_order = 1 (MultiATGCN.py:65-70,94-108): weights_g / weights_pool have ONE entry along k, yet the stack still is
+// [I, S_1, S_2, ...] (the Chebyshev loop at :98 is empty, :100 appends every first-order support) and einsum
+// 'bnki,nkio->bno' broadcasts the single weight over all of them: y = ((I + sum_s S_s) x) W.  Here: the dense
+// supports are SUMMED into one dense slot, the diagonal ones fold into the identity slot as usual, and every entry
+// reads pool index 0 - several stack entries may alias one pool index, which is why the backward walks entries.
 struct StackMap {
   int KtotOrig;                       // entries of weights_g / weights_pool along k
   int nKeep;                          // 1 (identity) + dense slots
-  int keepK[MATGCN_MAX_STACK];        // original k of every kept slot (keepK[0] = 0)
+  int keepK[MATGCN_MAX_STACK];        // pool index k of every kept slot (keepK[0] = 0)
   int nDiag;                          // folded (diagonal) slots
-  int diagK[MATGCN_MAX_STACK];        // original k of every folded slot
+  int diagK[MATGCN_MAX_STACK];        // pool index k of every folded slot
   int diagOrder[MATGCN_MAX_STACK];    // Chebyshev order of that slot (1 = the support itself)
   const float* diagSrc[MATGCN_MAX_STACK];  // (N,N) first-order support whose diagonal feeds it
   int N;
+};
+
+// What the pool gradients of the backward walk: one entry per stack entry that draws weights from the pools
+struct StackEntries {
+  int n;
+  int pool[2 * MATGCN_MAX_STACK];     // pool index k the entry reads
+  int slot[2 * MATGCN_MAX_STACK];     // node-GEMM slot whose weight gradient it takes (0 = identity)
+  int diag[2 * MATGCN_MAX_STACK];     // index into StackMap.diag* for a folded diagonal entry, else -1
 };
 
 // One launch of k_prep_stream writes, for a group of nodes, one piece of their weight streams:

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void k_adaptive_adj(const float* __restrict__ 
 }
 
 // static first-order supports (model.supports[s][1], MultiATGCN.py:269-283) -> transposed slots
+// (accumulate: add into the slot instead - cheb_order = 1 sums its dense supports, see StackMap)
 __global__ __launch_bounds__(256) void k_static_transpose(const float* __restrict__ S, int N, float* __restrict__ St,
-                                                          int ldS, int col0, float* __restrict__ plain, int ldP) {
+                                                          int ldS, int col0, float* __restrict__ plain, int ldP,
+                                                          int accumulate) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: m block, by: n block
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -96,7 +98,10 @@ __global__ __launch_bounds__(256) void k_static_transpose(const float* __restric
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int m = bx + j, n = by + tx;
-    if (m < N && n < N) St[(size_t)m * ldS + col0 + n] = tile[tx][j];
+    if (m < N && n < N) {
+      float* dst = &St[(size_t)m * ldS + col0 + n];
+      *dst = accumulate ? *dst + tile[tx][j] : tile[tx][j];
+    }
   }
 }
 

@@ -1,13 +1,20 @@
 // matgcn_node16.hip - node-wise contraction kernels of the recurrent step (included by matgcn_capi.hip).
 //
-// One workgroup (8 waves) per node n.  For that node the step needs
+// One workgroup (8 waves) per node n and 64-row block of the batch.  For that node the step needs
 //     Y[b][o] = sum_kk A[b][kk] * W_n[kk][o],   A[b] = [ s[b][n][0:64] | G[n][b][0:Ks][0:64] ]
 // (s = h for the gate AGCN, z*h for the update AGCN; G = graph-mixed s; MultiATGCN.py:106-108 restricted to the
-// recurrent rows - the x rows live in the hoisted pre-activation PX).  All 64 batch rows of the node sit in LDS
-// (80 KB at Ks = 4, so two workgroups share a CU and one's staging hides under the other's MFMAs); the
-// node-adaptive weights - the one big stream, 172 KB per node and step - go straight from L2/Infinity Cache into
-// each wave's registers in v_mfma_f32_16x16x4_f32 B-fragment order, four k-groups ahead, and are read exactly
-// once per workgroup.
+// recurrent rows - the x rows live in the hoisted pre-activation PX).
+//
+// The kernels sit at the ridge of the machine (32 FLOP per weight byte; ~100 MB per launch against ~2 GFLOP), so
+// what decides their time is whether the weight stream and the matrix pipe run AT THE SAME TIME.  Round 1 staged the
+// whole 64 x 256 A tile (64 KB) plus a ten-deep weight ring before the first MFMA: memory time and MFMA time added
+// up (21 + 17 us measured, tools/nodelab.hip).  Now the K range is walked in CHUNKS of 64 (one stack slot):
+//   chunk 0 = the 64 state rows (kept in LDS to the end: z*h / the blend need them), chunks 1..Ks = the mixed slots,
+//   ping-ponging through two 16 KB LDS buffers that are fed from registers two chunks ahead of the MFMAs;
+//   the node-adaptive weights - the one big stream, 131 / 65 KB per node and step - go straight from L2 / Infinity
+//   Cache into each wave's registers in v_mfma_f32_16x16x4_f32 B-fragment order, eight k-groups (two chunks) ahead.
+// The first MFMA issues after 24 KB have landed instead of 144 KB; what the epilogue adds (PX, R, previous state) is
+// requested before the last chunk; 48 / 64 KB of LDS.
 //
 // MFMA 16x16x4 f32 operand maps: A lane l -> A[row = l&15][k = l>>4], B lane l -> B[k = l>>4][col = l&15],
 // C/D lane l, reg e -> C[row = 4*(l>>4) + e][col = l&15].  A k-group is 16 reduction indices; MFMA step s of a
@@ -15,32 +22,44 @@
 //
 // LDS tile layout: rows of 16-byte slots; slot q of row r is stored at position q ^ (r & 15) inside its
 // 16-slot block, which makes the ds_read_b128 of lane (row, kq) conflict-free without padding.
+//
+// FRAGMENT-ORDERED intermediates: what one node kernel hands to the next for the SAME (node, row block) - the hoisted
+// pre-activation PX and the reset-blend gate R - is stored exactly as the producer's accumulators hold it,
+// [column tile][row tile][lane][4]: the producer's float4 IS the consumer's float4 (row 16 rt + 4 (l>>4) + e,
+// column 16 ct + (l&15)), so both sides move whole 1 KB wave rows and nothing is transposed.
 #ifndef MATGCN_NODE16_HIP
 #define MATGCN_NODE16_HIP
 
 // f32x4 / MFMA16 come from matgcn_kernels.hip (same translation unit)
 
-#ifndef N16_RING
-#define N16_RING 10   // k-groups of weights in flight per wave (10 KB): covers an Infinity-Cache round trip
+#ifndef NODE_MIN_WAVES
+#define NODE_MIN_WAVES 4   // __launch_bounds__ second argument: 4 waves per SIMD = a budget of 128 VGPRs (no spills).
+                           // 5 (96 VGPRs: two node waves per SIMD would fit beside five 64-VGPR graph-mix waves of the
+                           // other layer's chain) was measured in round 2: the forward got SLOWER (7.37 vs 7.17 ms) -
+                           // the spills cost more than co-residency gives, the two chains phase-lock anyway
 #endif
-#ifndef U16_RING
-#define U16_RING 6    // the same for k_update16: its waves stream half as many bytes per k-group, and the
-                      // residual-cell operands need the registers (10 spills)
+// (the weight ring of the K loop runs one 64-wide K chunk = 4 k-groups ahead of the MFMAs: 32-64 MFMAs per wave and
+// chunk, shared by up to four waves per SIMD, cover the round trip)
+#ifndef PX16_RING
+#define PX16_RING 4        // k_px16: two rings (two column tiles per wave)
 #endif
+#define NODE_PX_BLOCK 12288   // floats of one fragment-ordered PX block: 12 column tiles x 4 row tiles x 64 lanes x 4
+#define NODE_R_BLOCK 4096     // floats of one fragment-ordered R block: 4 column tiles x 4 row tiles x 64 lanes x 4
 
 struct Node16Args {
   const float* s;        // [rows][Np][64]: h (gate / res-only) or z*h (update)
   const float* g;        // [N][rows][Ks][64] graph-mixed s
   long gNodeStride;      // floats between the nodes of g; 0 = rows*Ks*64 (the block may sit inside a larger one)
   const float* w;        // [N][nG][OT][64][4] recurrent rows of the node-adaptive weights (fragment order)
-  const float* px;       // [N][rows][192] hoisted pre-activation of this step (x rows + bias): gate 0:128, update
-                         // 128:192 - layers >= 1; null for layer 0, whose narrow x part is contracted in the kernel:
+  const float* px;       // [N][RB][12][4][64][4] hoisted pre-activation of this step (x rows + bias), fragment order:
+                         // column tiles 0..7 gate, 8..11 update - layers >= 1; null for layer 0, whose narrow x part
+                         // is contracted in the kernel:
   const float* xa;       // [N][rows][16*nGx] folded x rows of this step [x | mix_k(x) | 1 | 0..] (layer 0) or null
   int nGx;               // k-groups of the x part (weights: groups nG .. nG+nGx-1 of the node's stream)
   int rows, N, Np, Ks;
   // gate
   float* zh;             // out [rows][Np][64]  z*h
-  float* r;              // gate: out / update: in  [N][rows][64]
+  float* r;              // gate: out / update: in  [N][RB][4][4][64][4] reset-blend gate, fragment order
   float* raw;            // optional (rows, N, 128) pre-activation dump (unit entry point)
   // update
   const float* h;        // [rows][Np][64] previous state (blend input)
@@ -86,150 +105,200 @@ __device__ __forceinline__ int swz(int row, int col, int spr) {
   return (row * spr + ((slot & ~15) | ((slot ^ row) & 15))) * 4 + (col & 3);
 }
 
-// stage the 64-row A tile of node n: Hs <- s rows (16 slots), Gs <- G rows (16*Ks slots); rows >= a.rows are zero.
-// All loads of a round are issued before the first LDS write and none sits behind a branch (a predicated load
-// would make the compiler wait for each one separately): out-of-range rows are clamped and zeroed by a select.
-__device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int rowBase, float* Hs, float* Gs) {
-  const int tid = threadIdx.x;
-  const int row = tid >> 4, q = tid & 15;          // 32 rows x 16 slots per sweep
-  const int rA = row, rB = row + 32;
-  const bool vA = rowBase + rA < a.rows, vB = rowBase + rB < a.rows;
-  const int gA = min(rowBase + rA, a.rows - 1), gB = min(rowBase + rB, a.rows - 1);
-  float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)gA * a.Np + n) * 64 + q * 4);
-  float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)gB * a.Np + n) * 64 + q * 4);
-  const int spr = 16 * a.Ks;
-  const float4* gsrc = reinterpret_cast<const float4*>(
-      a.g + (size_t)n * (a.gNodeStride ? (size_t)a.gNodeStride : (size_t)a.rows * spr * 4));
-  const int pA = q ^ (rA & 15), pB = q ^ (rB & 15);
-  if (a.Ks == 0) {   // no dense support left (all folded): only the s slots
-    *reinterpret_cast<float4*>(&Hs[(rA * 16 + pA) * 4]) = keep4(vA, hA);
-    *reinterpret_cast<float4*>(&Hs[(rB * 16 + pB) * 4]) = keep4(vB, hB);
+// ---- K-chunk pipeline shared by k_gate16 and k_update16 --------------------------------------------------------
+// staging coordinates of a thread: rows srow and srow + 32 of a chunk, 16-byte slot sq
+struct ChunkStage {
+  int srow, sq, gA, gB;      // gA / gB: the two global rows (clamped into range: loads are never predicated, a
+  bool vA, vB;               //          predicated load would make the compiler wait for each one separately)
+  const float4* gsrc;        // this node's mixed rows [rows][Ks][16 slots]
+  int spr;                   // slots per mixed row = 16 * Ks
+};
+
+__device__ __forceinline__ ChunkStage chunk_stage(const Node16Args& a, int n, int rowBase) {
+  ChunkStage c;
+  c.srow = threadIdx.x >> 4; c.sq = threadIdx.x & 15;
+  c.vA = rowBase + c.srow < a.rows; c.vB = rowBase + c.srow + 32 < a.rows;
+  c.gA = min(rowBase + c.srow, a.rows - 1); c.gB = min(rowBase + c.srow + 32, a.rows - 1);
+  c.spr = 16 * a.Ks;
+  c.gsrc = reinterpret_cast<const float4*>(
+      a.g + (size_t)n * (a.gNodeStride ? (size_t)a.gNodeStride : (size_t)a.rows * c.spr * 4));
+  return c;
+}
+
+// request chunk c (1..Ks) = mixed slot c-1 of this node's rows
+__device__ __forceinline__ void chunk_load(const ChunkStage& c, int Ks, int chunk, float4 (&r)[2]) {
+  const int k = max(min(chunk, Ks) - 1, 0);
+  r[0] = c.gsrc[(size_t)c.gA * c.spr + k * 16 + c.sq];
+  r[1] = c.gsrc[(size_t)c.gB * c.spr + k * 16 + c.sq];
+}
+
+// registers -> one [64 rows][16 slots] swizzled LDS chunk; rows beyond a.rows are zero
+__device__ __forceinline__ void chunk_store(float* buf, const ChunkStage& c, const float4& ra, const float4& rb) {
+  const int rA = c.srow, rB = c.srow + 32;
+  *reinterpret_cast<float4*>(&buf[(rA * 16 + (c.sq ^ (rA & 15))) * 4]) = keep4(c.vA, ra);
+  *reinterpret_cast<float4*>(&buf[(rB * 16 + (c.sq ^ (rB & 15))) * 4]) = keep4(c.vB, rb);
+}
+
+// The four k-groups of one chunk for NRT row tiles starting at tile rt0.  The weights of a chunk wait in one HALF of
+// the ring (wr[PAR]); the four k-groups of the NEXT chunk are requested into the other half BEFORE this chunk's first
+// MFMA (a refill of the half being read could only issue after the MFMAs that read it: round 2 measured exactly that
+// - the loads bunched up at the end of the chunk and the next chunk began by waiting for them).  A fragments come from
+// the LDS chunk; accumulators rotate so that a chain is revisited every NRT-th instruction.
+template <int NRT, int PAR, bool PREFETCH>
+__device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int kq, float4 (&wr)[2][4], const float4* wp,
+                                           size_t gStride, int gNext, int gLast, f32x4 (&acc)[NRT]) {
+  if (PREFETCH) {
+#ifdef NODE_LAB_NO_WEIGHTS   // tools/nodelab2.hip: every k-group re-reads the node's first one (an L1 hit)
+    gNext = 0; gLast = 0;
+#endif
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl) wr[PAR ^ 1][gl] = wp[(size_t)min(gNext + gl, gLast) * gStride];
+    // the scheduler would otherwise sink these loads below the chunk's MFMAs to shorten their live ranges
+    __builtin_amdgcn_sched_barrier(0);
   }
-  for (int k0 = 0; k0 < a.Ks; k0 += 4) {
-    float4 vAk[4], vBk[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int k = min(k0 + kk, a.Ks - 1);
-      vAk[kk] = gsrc[(size_t)gA * spr + k * 16 + q];
-      vBk[kk] = gsrc[(size_t)gB * spr + k * 16 + q];
-    }
-    if (k0 == 0) {
-      *reinterpret_cast<float4*>(&Hs[(rA * 16 + pA) * 4]) = keep4(vA, hA);
-      *reinterpret_cast<float4*>(&Hs[(rB * 16 + pB) * 4]) = keep4(vB, hB);
-    }
+  for (int gl = 0; gl < 4; ++gl) {
+    float4 av[NRT];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (k0 + kk < a.Ks) {
-        *reinterpret_cast<float4*>(&Gs[(rA * spr + (k0 + kk) * 16 + pA) * 4]) = keep4(vA, vAk[kk]);
-        *reinterpret_cast<float4*>(&Gs[(rB * spr + (k0 + kk) * 16 + pB) * 4]) = keep4(vB, vBk[kk]);
+    for (int q = 0; q < NRT; ++q)
+      av[q] = *reinterpret_cast<const float4*>(&buf[(((rt0 + q) * 16 + j) * 16 + ((4 * gl + kq) ^ j)) * 4]);
+    const float4 wv = wr[PAR][gl];
+#ifdef NODE_LAB_NO_MFMA   // tools/nodelab2.hip: the same operand traffic without the matrix pipe
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) acc[q][0] += av[q].x * wv.x + av[q].y * wv.y + av[q].z * wv.z + av[q].w * wv.w;
+#else
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
+#pragma unroll
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
+#endif
+  }
+}
+
+// The whole recurrent K range of one node: acc[q] = [s | G][rows of tiles rt0..rt0+NRT-1] . W_n[:, this wave's tile]
+// Hs: chunk 0 (left in place), Gb: the two ping-pong buffers.  Every thread of the workgroup must call it (barriers);
+// on return every wave may still be inside the last chunk's MFMAs.
+// What is requested before the first MFMA decides how long the matrix pipe idles at the start of the launch (all
+// workgroups of a launch start together): only the 16 KB of state rows and the first k-groups of weights come first;
+// the mixed chunks follow, and everything the epilogue adds (PX, R, the previous state, the narrow x part of layer 0)
+// is requested by `late()` just before the LAST chunk's MFMAs (one call site: the last chunk is peeled).
+//   schedule   request s rows, the weights of chunk 0, chunks 1 and 2;  Hs <- s;  barrier;
+//              chunk 0 from Hs (weights of chunk 1 requested first);  Gb[0] <- chunk 1, Gb[1] <- chunk 2, request
+//              chunks 3 and 4;  barrier;
+//              for c = 1..Ks-1:  request the weights of chunk c+1, chunk c from Gb[(c-1)&1];  barrier;
+//                                Gb[(c-1)&1] <- chunk c+2, request chunk c+4
+//              late();  chunk Ks
+template <int NRT, typename Late>
+__device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowBase, float* Hs, float* Gb, int rt0, int j,
+                                            int kq, const float4* wp, size_t gStride, f32x4 (&acc)[NRT], Late&& late) {
+  const int Ks = a.Ks, gLast = 4 * (1 + Ks) - 1;
+  const ChunkStage cs = chunk_stage(a, n, rowBase);
+  const float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gA * a.Np + n) * 64 + cs.sq * 4);
+  const float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gB * a.Np + n) * 64 + cs.sq * 4);
+  float4 wr[2][4];       // weight ring: chunk c reads half c & 1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wr[0][r] = wp[(size_t)min(r, gLast) * gStride];
+  // staging registers: chunk c waits in st[c & 1].  Every request below is UNCONDITIONAL (the chunk index is clamped, a
+  // request past the last chunk re-reads it from L2): a load behind a branch makes the number of loads in flight depend
+  // on the path, and the compiler then drains the whole queue (vmcnt(0)) where the paths meet - at the loop head
+  float4 st[2][2];
+  chunk_load(cs, Ks, 1, st[1]);
+  chunk_load(cs, Ks, 2, st[0]);
+#pragma unroll
+  for (int q = 0; q < NRT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  chunk_store(Hs, cs, hA, hB);
+  __syncthreads();
+  if (Ks > 0) {
+    chunk_mfma<NRT, 0, true>(Hs, rt0, j, kq, wr, wp, gStride, 4, gLast, acc);
+    chunk_store(Gb, cs, st[1][0], st[1][1]);
+    if (Ks > 1) chunk_store(Gb + 4096, cs, st[0][0], st[0][1]);
+    chunk_load(cs, Ks, 3, st[1]);
+    chunk_load(cs, Ks, 4, st[0]);
+    __syncthreads();
+    for (int c = 1; c < Ks; c += 2) {
+      // odd chunk c (not the last) in Gb[0]; afterwards Gb[0] <- chunk c+2 (waiting in st[1])
+      chunk_mfma<NRT, 1, true>(Gb, rt0, j, kq, wr, wp, gStride, 4 * (c + 1), gLast, acc);
+      __syncthreads();
+      if (c + 2 <= Ks) chunk_store(Gb, cs, st[1][0], st[1][1]);
+      chunk_load(cs, Ks, c + 4, st[1]);
+      if (c + 1 < Ks) {  // even chunk c+1 (not the last) in Gb[1]; afterwards Gb[1] <- chunk c+3 (waiting in st[0])
+        chunk_mfma<NRT, 0, true>(Gb + 4096, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
+        __syncthreads();
+        if (c + 3 <= Ks) chunk_store(Gb + 4096, cs, st[0][0], st[0][1]);
+        chunk_load(cs, Ks, c + 5, st[0]);
       }
     }
   }
+  late();
+  if (Ks & 1) chunk_mfma<NRT, 1, false>(Gb, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);               // odd last chunk
+  else chunk_mfma<NRT, 0, false>(Ks > 0 ? Gb + 4096 : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
 }
 
-// A fragment of row tile rt for k-group g (g < 4: the s slots, else the mixed slots)
-__device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int Ks, int rt, int g, int i, int kq) {
-  const int row = rt * 16 + i;
-  if (g < 4) return *reinterpret_cast<const float4*>(&Hs[(row * 16 + ((4 * g + kq) ^ i)) * 4]);
-  const int q = 4 * (g - 4) + kq;
-  return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
-}
-
-// the 16 MFMAs of one k-group: 4 row tiles x 4 k-steps, accumulators rotate so that a chain is revisited every
-// fourth instruction
-__device__ __forceinline__ void mfma_group(const float4 (&av)[4], const float4& wv, f32x4 (&acc)[4]) {
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
-}
-
-// layer-0 x part: acc[rt] += XA[rows of tile rt][16 gx .. +16] . Wx[gx]; A fragments come straight from global
+// layer-0 x part: acc[q] += XA[rows of tile rt0+q][16 gx .. +16] . Wx[gx]; A fragments come straight from global
 // memory (a row of XA is 64*nGx bytes, a 16-row tile is contiguous), weights from the tail of the node's stream
-__device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, const float4* wx, int gStride, int i,
-                                         int kq, f32x4 (&acc)[4]) {
+template <int NRT>
+__device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, int rt0, const float4* wx, size_t gStride,
+                                         int i, int kq, f32x4 (&acc)[NRT]) {
   const int kx = 16 * a.nGx;
   const float* base = a.xa + (size_t)n * a.rows * kx + kq * 4;
   for (int gx = 0; gx < a.nGx; ++gx) {
     const float4 wv = wx[(size_t)gx * gStride];
-    float4 av[4];
+    float4 av[NRT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-      av[rt] = *reinterpret_cast<const float4*>(base + (size_t)min(rowBase + rt * 16 + i, a.rows - 1) * kx + gx * 16);
+    for (int q = 0; q < NRT; ++q)
+      av[q] = *reinterpret_cast<const float4*>(base + (size_t)min(rowBase + (rt0 + q) * 16 + i, a.rows - 1) * kx + gx * 16);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wv.x, acc[rt]);
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wv.y, acc[rt]);
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wv.z, acc[rt]);
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wv.w, acc[rt]);
+    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
   }
 }
 
+__device__ __forceinline__ f32x4 as_f32x4(const float4& v) { return f32x4{v.x, v.y, v.z, v.w}; }
+
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
+// wave w = column tile w of 8 (0..3: z, 4..7: r), all four row tiles.  LDS 48 KB: Hs | Gb[2]
 template <bool SAVE>
-__global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
+__global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_gate16(Node16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Hs = lds;               // [64][16 slots]
-  float* Gs = lds + 64 * 64;     // [64][16*Ks slots]
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  float* Hs = lds;               // [64][16 slots] the state rows: chunk 0, and the h of z*h
+  float* Gb = lds + 4096;        // 2 x [64][16 slots] mixed-slot chunks; afterwards the z*h output tile
+  const int n = blockIdx.x, rb = blockIdx.y, RB = gridDim.y, rowBase = rb * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + a.Ks);
-  // weight stream of this wave: column tile w (of 8)
+  const size_t gStride = 8 * 64;
   const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
-  stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
-  float4 wr[N16_RING];
-#pragma unroll
-  for (int r = 0; r < N16_RING; ++r) wr[r] = wp[(size_t)min(r, nG - 1) * 8 * 64];
-  // accumulators start from the hoisted pre-activation (x rows + bias), fetched while the tile lands;
-  // layer 0 instead contracts its narrow x part here, straight from global memory, before the tile is needed
-  const int o = 16 * w + j;
   f32x4 acc[4];
-  if (a.px) {
+  float4 pxv[4];                 // hoisted pre-activation (x rows + bias) in fragment order, added in the epilogue
+  node_k_loop<4>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
+    if (a.px) {
+      const float4* pf = reinterpret_cast<const float4*>(a.px) + (((size_t)n * RB + rb) * 12 + w) * 4 * 64 + lane;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < 4; ++rt) pxv[rt] = pf[rt * 64];
+    } else {   // layer 0 contracts its narrow x part here, straight from global memory
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
-        acc[rt][e] = a.px[((size_t)n * a.rows + b) * 192 + o];
-      }
-  } else {
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    x_groups(a, n, rowBase, wp + (size_t)nG * 8 * 64, 8 * 64, j, kq, acc);
-  }
-  __syncthreads();
-  // k-groups in pairs: the A fragments of a group are read from LDS while the MFMAs of the group before it run
-  // (two named fragment sets ping-pong; nG is even)
-  float4 avA[4], avB[4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, 0, j, kq);
-  for (int g0 = 0; g0 < nG; g0 += N16_RING) {
-#pragma unroll
-    for (int r = 0; r < N16_RING; r += 2) {
-      const int g = g0 + r;
-      const float4 w0 = wr[r], w1 = wr[r + 1];
-      wr[r] = wp[(size_t)min(g + N16_RING, nG - 1) * 8 * 64];
-      wr[r + 1] = wp[(size_t)min(g + 1 + N16_RING, nG - 1) * 8 * 64];
-      if (g < nG) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) avB[rt] = a_frag(Hs, Gs, a.Ks, rt, g + 1, j, kq);
-        mfma_group(avA, w0, acc);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, min(g + 2, nG - 1), j, kq);
-        mfma_group(avB, w1, acc);
-      }
+      for (int rt = 0; rt < 4; ++rt) pxv[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      x_groups<4>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
     }
+  });
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    acc[rt][0] += pxv[rt].x; acc[rt][1] += pxv[rt].y; acc[rt][2] += pxv[rt].z; acc[rt][3] += pxv[rt].w;
   }
-  // epilogue: zr = sigmoid(.), z*h and r gathered as a [64 rows][z*h 64 | r 64] tile in LDS (the mixed slots are
-  // dead once every wave has left the K loop), then written out as whole 256-byte rows
+  // epilogue: zr = sigmoid(.);  r leaves in fragment order straight from the accumulators (the update kernel of
+  // this node reads it back the same way); z*h is gathered as a [64][64] tile in LDS (the chunk buffers are dead once
+  // every wave has left the K loop) and written out as whole 256-byte rows of the next mix's operand
   __syncthreads();
-  float* Out = Gs;                                  // [64][32 slots], same XOR swizzle as the tiles
+  float* Out = Gb;
+  const int o = 16 * w + j;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
@@ -239,54 +308,95 @@ __global__ __launch_bounds__(512, 4) void k_gate16(Node16Args a) {
       if (a.raw && b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
       const float sg = sigmoid16(v);
       if (SAVE && b < a.rows) ((w < 4) ? a.svZ : a.svR)[((size_t)b * a.Np + n) * 64 + (o & 63)] = sg;
-      Out[swz(lb, o, 32)] = (w < 4) ? sg * Hs[swz(lb, o, 16)] : sg;
+      if (w < 4) Out[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
+      else acc[rt][e] = sg;
     }
+  }
+  if (w >= 4) {
+    const size_t base = ((((size_t)n * RB + rb) * 4 + (w - 4)) * 4) * 256 + (size_t)lane * 4;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+      store_wt16(a.r, base + (size_t)rt * 256, make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]));
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {                  // 64 rows x 32 slots = 2048 float4 over 512 threads
-    const int idx = tid + 512 * it;
-    const int lb = idx >> 5, q = idx & 31, b = rowBase + lb;
+  for (int it = 0; it < 2; ++it) {                  // 64 rows x 16 slots = 1024 float4 over 512 threads
+    const int lb = (tid >> 4) + 32 * it, q = tid & 15, b = rowBase + lb;
     if (b >= a.rows) continue;
-    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 32 + ((q & ~15) | ((q ^ lb) & 15))) * 4]);
-    if (q < 16) store_wt16(a.zh, ((size_t)b * a.Np + n) * 64 + q * 4, v);
-    else store_wt16(a.r, ((size_t)n * a.rows + b) * 64 + (q - 16) * 4, v);
+    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (q ^ (lb & 15))) * 4]);
+    store_wt16(a.zh, ((size_t)b * a.Np + n) * 64 + q * 4, v);
   }
 }
 
-// ---- hoisted x part of layers >= 1: PX[t][n][b][0:192] = bias[n] + [x | mix_k(x)] . Wx[n] --------------------
-// (MultiATGCN.py:106-108 restricted to the x rows; gate columns 0:128, update columns 128:192.)  Same structure as
-// the gate kernel - 64-row tile [x | G] of one node in LDS, weights streamed once per workgroup - with 12 column
-// tiles over 8 waves: waves 0-3 take two tiles, waves 4-7 one, i.e. three per SIMD.  rows = B * (steps of the
-// chunk), row -> (t, b) t-major; workgroup ids of one node's row blocks are 8 apart (same XCD, same time: the
-// second and later blocks read the node's weights from that XCD's L2).
-#ifndef PX16_RING
-#define PX16_RING 4   // two rings (two column tiles per wave); 6 spills to scratch (-11 %)
-#endif
+// ---- hoisted x part of layers >= 1: PX[t][n][rb] = bias[n] + [x | mix_k(x)] . Wx[n], fragment order ---------------
+// (MultiATGCN.py:106-108 restricted to the x rows; gate column tiles 0..7, update column tiles 8..11.)  64-row tile
+// [x | G] of one (node, step, row block) in LDS, weights streamed once per workgroup, 12 column tiles over 8 waves:
+// waves 0-3 take two tiles, waves 4-7 one, i.e. three per SIMD.  Workgroup ids of one node's blocks are 8 apart
+// (same XCD, same time: the second and later blocks read the node's weights from that XCD's L2).
 struct Px16Args {
-  const float* x;        // [rows][Np][64] input rows of the chunk (layer below, time-major)
-  const float* g;        // [N][rows][Ks][64] graph-mixed input rows
+  const float* x;        // [steps*B][Np][64] input rows of the chunk (layer below, time-major)
+  const float* g;        // [N][steps*B][Ks][64] graph-mixed input rows
   const float* w;        // [N][nG][12][64][4] x rows of both AGCNs (fragment order)
   const float* bias;     // [N][192]
-  float* pxOut;          // [Tc][N][B][192] slice of PX
-  int rows, N, Np, Ks, B;
+  float* pxOut;          // [steps][N][RB][12][4][64][4] slice of PX
+  int steps, N, Np, Ks, B;
 };
+
+// stage the whole 64-row A tile of a (node, step, row block): Hs <- x rows (16 slots), Gs <- G rows (16*Ks slots)
+__device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int rowBase, float* Hs, float* Gs) {
+  const ChunkStage cs = chunk_stage(a, n, rowBase);
+  const float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gA * a.Np + n) * 64 + cs.sq * 4);
+  const float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gB * a.Np + n) * 64 + cs.sq * 4);
+  const int rA = cs.srow, rB = cs.srow + 32;
+  const int pA = cs.sq ^ (rA & 15), pB = cs.sq ^ (rB & 15);
+  const int spr = cs.spr;
+  if (a.Ks == 0) chunk_store(Hs, cs, hA, hB);
+  for (int k0 = 0; k0 < a.Ks; k0 += 4) {
+    float4 vAk[4], vBk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = min(k0 + kk, a.Ks - 1);
+      vAk[kk] = cs.gsrc[(size_t)cs.gA * spr + k * 16 + cs.sq];
+      vBk[kk] = cs.gsrc[(size_t)cs.gB * spr + k * 16 + cs.sq];
+    }
+    if (k0 == 0) chunk_store(Hs, cs, hA, hB);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (k0 + kk < a.Ks) {
+        *reinterpret_cast<float4*>(&Gs[(rA * spr + (k0 + kk) * 16 + pA) * 4]) = keep4(cs.vA, vAk[kk]);
+        *reinterpret_cast<float4*>(&Gs[(rB * spr + (k0 + kk) * 16 + pB) * 4]) = keep4(cs.vB, vBk[kk]);
+      }
+    }
+  }
+}
+
+// A fragment of row tile rt for k-group g (g < 4: the x slots, else the mixed slots) of the whole-tile layout
+__device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int Ks, int rt, int g, int i, int kq) {
+  const int row = rt * 16 + i;
+  if (g < 4) return *reinterpret_cast<const float4*>(&Hs[(row * 16 + ((4 * g + kq) ^ i)) * 4]);
+  const int q = 4 * (g - 4) + kq;
+  return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
+}
+
 __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;
   float* Gs = lds + 64 * 64;
-  const int RB = (p.rows + 63) >> 6;
+  const int RB = (p.B + 63) >> 6, blocks = p.steps * RB;
   const int id = blockIdx.x;
-  const int grp = id / (8 * RB), rem = id - grp * 8 * RB;
-  const int n = grp * 8 + (rem & 7), rowBase = (rem >> 3) * 64;
+  const int grp = id / (8 * blocks), rem = id - grp * 8 * blocks;
+  const int n = grp * 8 + (rem & 7), blk = rem >> 3;
   if (n >= p.N) return;
+  const int tl = blk / RB, rb = blk - tl * RB, rowBase = rb * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + p.Ks);
   const bool two = w < 4;                       // this wave also owns column tile w + 8
   const float4* wp0 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
   const float4* wp1 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + min(w + 8, 11)) * 64 + lane;
-  Node16Args a;                                 // staging helper speaks Node16Args
-  a.s = p.x; a.g = p.g; a.gNodeStride = 0; a.rows = p.rows; a.Np = p.Np; a.Ks = p.Ks;
+  Node16Args a;                                 // the staging helper speaks Node16Args: the B rows of step tl
+  a.s = p.x + (size_t)tl * p.B * p.Np * 64;
+  a.g = p.g + (size_t)tl * p.B * p.Ks * 64; a.gNodeStride = (long)p.steps * p.B * p.Ks * 64;
+  a.rows = p.B; a.Np = p.Np; a.Ks = p.Ks;
   stage_node_tile(a, n, rowBase, Hs, Gs);
   float4 wr0[PX16_RING], wr1[PX16_RING];
 #pragma unroll
@@ -332,136 +442,80 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
       }
     }
   }
+  // the accumulators leave as they are: one 1 KB wave row per (column tile, row tile)
+  float4* dst = reinterpret_cast<float4*>(p.pxOut) + (((size_t)tl * p.N + n) * RB + rb) * (NODE_PX_BLOCK / 4) + lane;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = rowBase + rt * 16 + 4 * kq + e;
-      if (row >= p.rows) continue;
-      const int t = row / p.B, b = row - t * p.B;
-      float* dst = p.pxOut + (((size_t)t * p.N + n) * p.B + b) * 192;
-      dst[o0] = acc0[rt][e];
-      if (two) dst[o1] = acc1[rt][e];
-    }
+  for (int rt = 0; rt < 4; ++rt) {
+    dst[((size_t)w * 4 + rt) * 64] = make_float4(acc0[rt][0], acc0[rt][1], acc0[rt][2], acc0[rt][3]);
+    if (two) dst[((size_t)(w + 8) * 4 + rt) * 64] = make_float4(acc1[rt][0], acc1[rt][1], acc1[rt][2], acc1[rt][3]);
+  }
 }
 
 // ---- update AGCN + tanh + GRU blend, fused with the residual GRU cell and the per-step blend ------------------
 // MODE 0: ATGRU update only (h' out); 1: update + residual cell (+ blend); 2: residual cell only on s (unit entry)
 //
-// Waves: (ct = w&3, kh = w>>2).  The update GEMM (O = 64: 4 column tiles) splits K in two halves over the wave
-// pairs so that every weight fragment is still fetched exactly once; the halves meet in LDS.  The residual cell
-// then runs two small GEMMs on tiles that never leave LDS.  Every global operand of a later phase is requested
-// before the barrier of the phase in front of it, so its latency hides under that phase.
+// Waves: (ct = w&3, rh = w>>2) = column tile ct of 4, row tiles 2rh and 2rh+1, the whole K range (the two waves of a
+// column tile request the same weight fragments: the second request is an L1 / L2 hit, HBM sees each byte once).
+// The residual cell then runs two small GEMMs on tiles that never leave LDS.  LDS 64 KB: Hs | Gb[2] | X
 template <int MODE, bool SAVE>
-__global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
+__global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Hs = lds;               // [64][16 slots]: z*h during the update GEMM, then h'
-  float* Gs = lds + 64 * 64;     // [64][16*Ks slots]; reused afterwards (>= 64 KB is allocated):
-  float* Red = Gs;               //   [4 ct][4 rt][64 lanes][4]  K-half partial sums          16 KB
-  float* ZH2 = Gs + 4096;        //   [64][16 slots] z2*h'                                      16 KB
-  float* R2 = Gs + 2 * 4096;     //   [64][16 slots] r2                                         16 KB
-  float* XT = Gs + 3 * 4096;     //   [64][16 slots] x_t (zero padded)                          16 KB
-  const int n = blockIdx.x, rowBase = blockIdx.y * 64;
+  float* Hs = lds;               // [64][16 slots]: z*h (chunk 0) during the update GEMM, then h'
+  float* Gb = lds + 4096;        // 2 x [64][16 slots] mixed-slot chunks; reused by the residual cell:
+  float* ZH2 = Gb;               //   [64][16 slots] z2*h'
+  float* R2 = Gb + 4096;         //   [64][16 slots] r2
+  float* XT = lds + 3 * 4096;    // [64][16 slots] x_t (zero padded); afterwards the output tile
+  const int n = blockIdx.x, rb = blockIdx.y, RB = gridDim.y, rowBase = rb * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
-  const int ct = w & 3, kh = w >> 2;
+  const int ct = w & 3, rh = w >> 2;
   const int srow = tid >> 4, sq = tid & 15;   // staging coordinates: 32 rows x 16 slots per sweep
+  const int o4 = 16 * ct + j;                 // column of this lane in a 64-wide tile
 
-  f32x4 acc[4];
   if (MODE != 2) {
-    const int nG = 4 * (1 + a.Ks), nGh = nG >> 1;   // nG is even: each K half is nGh groups
-    const int gBeg = kh * nGh;
+    const int nG = 4 * (1 + a.Ks);
+    const size_t gStride = 4 * 64;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
-    stage_node_tile(a, n, rowBase, Hs, Gs);   // requested first: the MFMAs cannot start without the tile
-    float4 wr[U16_RING];
-#pragma unroll
-    for (int r = 0; r < U16_RING; ++r) wr[r] = wp[(size_t)(gBeg + min(r, nGh - 1)) * 4 * 64];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!a.px && kh == 0) x_groups(a, n, rowBase, wp + (size_t)nG * 4 * 64, 4 * 64, j, kq, acc);   // layer 0
-    __syncthreads();
-    // k-groups in pairs, A fragments one group ahead of the MFMAs (see k_gate16); nGh is even
-    float4 avA[4], avB[4];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg, j, kq);
-    for (int g0 = 0; g0 < nGh; g0 += U16_RING) {
-#pragma unroll
-      for (int r = 0; r < U16_RING; r += 2) {
-        const int gl = g0 + r;
-        const float4 w0 = wr[r], w1 = wr[r + 1];
-        wr[r] = wp[(size_t)(gBeg + min(gl + U16_RING, nGh - 1)) * 4 * 64];
-        wr[r + 1] = wp[(size_t)(gBeg + min(gl + 1 + U16_RING, nGh - 1)) * 4 * 64];
-        if (gl < nGh) {
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) avB[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg + gl + 1, j, kq);
-          mfma_group(avA, w0, acc);
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) avA[rt] = a_frag(Hs, Gs, a.Ks, rt, gBeg + min(gl + 2, nGh - 1), j, kq);
-          mfma_group(avB, w1, acc);
-        }
+    f32x4 acc[2];
+    // epilogue operands, requested just before the last chunk: PX and r in fragment order (r as k_gate16 left it),
+    // the previous state row-major
+    float4 pxv[2], rv[2];
+    float hv[2][4];
+    node_k_loop<2>(a, n, rowBase, Hs, Gb, 2 * rh, j, kq, wp, gStride, acc, [&]() {
+      if (a.px) {
+        const float4* pf = reinterpret_cast<const float4*>(a.px) + ((((size_t)n * RB + rb) * 12 + 8 + ct) * 4 + 2 * rh) * 64 + lane;
+        pxv[0] = pf[0]; pxv[1] = pf[64];
+      } else {
+        pxv[0] = make_float4(0.f, 0.f, 0.f, 0.f); pxv[1] = pxv[0];
+        x_groups<2>(a, n, rowBase, 2 * rh, wp + (size_t)nG * gStride, gStride, j, kq, acc);
       }
-    }
-  }
-
-  // ---- operands of the next phases, requested now ----
-  const int o4 = 16 * ct + j;                      // column of this lane in a 64-wide tile
-  float pxv[4][4], rv[4][4], hv[4][4];             // blend operands (kh == 0 waves use them)
-  if (MODE != 2) {
+      const float4* rf = reinterpret_cast<const float4*>(a.r) + ((((size_t)n * RB + rb) * 4 + ct) * 4 + 2 * rh) * 64 + lane;
+      rv[0] = rf[0]; rv[1] = rf[64];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1);
-        pxv[rt][e] = a.px ? a.px[((size_t)n * a.rows + b) * 192 + 128 + o4] : 0.f;
-        rv[rt][e] = a.r[((size_t)n * a.rows + b) * 64 + o4];
-        hv[rt][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
-      }
-  }
-  const int ngx = a.Cpad >> 4;                     // x groups of the residual GEMMs (1 or 4)
-  const int nG1 = ngx + 4;                         // <= 8
-  float4 xv[2];
-  float xs[2][4];
-  if (MODE != 0) {
-    if (a.C == 64) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-        xv[it] = *reinterpret_cast<const float4*>(a.xt + (size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.xRowStride +
-                                                  (size_t)n * 64 + sq * 4);
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int c = min(sq * 4 + cc, a.C - 1);
-          xs[it][cc] = a.xt[(size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.xRowStride + (size_t)n * a.C + c];
-        }
-    }
-  }
-
-  if (MODE != 2) {
-    __syncthreads();   // every wave is done with the mixed slots: Gs becomes scratch
-    if (kh == 1) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-        *reinterpret_cast<f32x4*>(&Red[((ct * 4 + rt) * 64 + lane) * 4]) = acc[rt];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(&Red[((ct * 4 + rt) * 64 + lane) * 4]);
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
-          const float hc = tanhf(acc[rt][e] + p[e] + pxv[rt][e]);
-          const float rr = rv[rt][e];
-          float hn = rr * hv[rt][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
-          if (SAVE && b < a.rows) a.svHC[((size_t)b * a.Np + n) * 64 + o4] = hc;
-          if (b >= a.rows) hn = 0.f;
-          if (MODE == 0) { if (b < a.rows) a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn; }
-          else Hs[swz(lb, o4, 16)] = hn;                  // h' tile for the residual cell (z*h no longer needed)
+          const int b = min(rowBase + (2 * rh + q) * 16 + 4 * kq + e, a.rows - 1);
+          hv[q][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
         }
-      }
+    });
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      acc[q][0] += pxv[q].x; acc[q][1] += pxv[q].y; acc[q][2] += pxv[q].z; acc[q][3] += pxv[q].w;
     }
+    __syncthreads();   // every wave is out of the K loop: Hs (z*h) may be overwritten by h'
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lb = (2 * rh + q) * 16 + 4 * kq + e, b = rowBase + lb;
+        const float hc = tanhf(acc[q][e]);
+        const float rr = e == 0 ? rv[q].x : e == 1 ? rv[q].y : e == 2 ? rv[q].z : rv[q].w;
+        float hn = rr * hv[q][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
+        if (SAVE && b < a.rows) a.svHC[((size_t)b * a.Np + n) * 64 + o4] = hc;
+        if (b >= a.rows) hn = 0.f;
+        if (MODE == 0) { if (b < a.rows) a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn; }
+        else Hs[swz(lb, o4, 16)] = hn;                  // h' tile for the residual cell (z*h no longer needed)
+      }
     if (MODE == 0) return;
   } else {
     // residual cell only: h' := s rows
@@ -477,29 +531,34 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
   }
 
   // ---- residual GRU cell on [x_t | h'] (MultiATGCN.py:142-150) ----
+  const int ngx = a.Cpad >> 4;                     // x groups of the residual GEMMs (1 or 4)
+  const int nG1 = ngx + 4;                         // <= 8
 #pragma unroll
   for (int it = 0; it < 2; ++it) {   // x_t tile (zero padded to Cpad)
     const int rr = srow + 32 * it;
     const bool ok = rowBase + rr < a.rows;
+    const size_t xrow = (size_t)min(rowBase + rr, a.rows - 1) * a.xRowStride;
     if (a.C == 64) {
-      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(ok, xv[it]);
+      const float4 xv = *reinterpret_cast<const float4*>(a.xt + xrow + (size_t)n * 64 + sq * 4);
+      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(ok, xv);
     } else if (sq < (a.Cpad >> 2)) {
       float e4[4];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) e4[cc] = (ok && sq * 4 + cc < a.C) ? xs[it][cc] : 0.f;
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = min(sq * 4 + cc, a.C - 1);
+        const float xv = a.xt[xrow + (size_t)n * a.C + c];
+        e4[cc] = (ok && sq * 4 + cc < a.C) ? xv : 0.f;
+      }
       *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
     }
   }
   // weights of both residual GEMMs (shared by all nodes, L2-resident), requested before the tile barrier
-  const int rp = kh;
-  float4 rgv[8], ruv[8];
+  const int rp = rh;
+  float4 rgv[8];
   {
     const float4* rgp = reinterpret_cast<const float4*>(a.rg) + (size_t)w * 64 + lane;
 #pragma unroll
     for (int g = 0; g < 8; ++g) rgv[g] = rgp[(size_t)min(g, nG1 - 1) * 8 * 64];
-    const float4* rup = reinterpret_cast<const float4*>(a.ru) + (size_t)ct * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) ruv[g] = rup[(size_t)min(g, nG1 - 1) * 4 * 64];
   }
   const float bg = a.rgb[16 * w + j], bu = a.rub[o4];
   const float gate = a.blend ? sigmoid16(a.blend[0]) : 0.f;   // g = sigmoid(weights_gru[l][t]) (:208)
@@ -526,6 +585,13 @@ __global__ __launch_bounds__(512, 4) void k_update16(Node16Args a) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].w, wv.w, acc1[rt]);
     }
+  }
+  // the weights of GEMM 2 are requested now (the registers of GEMM 1's weights are free): they land under the sigmoids
+  float4 ruv[8];
+  {
+    const float4* rup = reinterpret_cast<const float4*>(a.ru) + (size_t)ct * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ruv[g] = rup[(size_t)min(g, nG1 - 1) * 4 * 64];
   }
   {
     const int o = 16 * w + j;

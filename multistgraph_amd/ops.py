@@ -481,28 +481,32 @@ class HotPath:
         return out
 
     def supports(self) -> torch.Tensor:
-        """(K-1, N, N) non-identity supports in the reference's stack order (tests): the dense slots come from
-        the stack built by matgcn_prepare, the folded (diagonal) ones are re-expanded from their diagonals."""
+        """(Ks, N, N): the DENSE non-identity slots of the support stack as matgcn_prepare built them, in stack order
+        (tests).  Diagonal supports never reach the stack - they are folded into the identity slot of the node-adaptive
+        weights (read those back with node_weights) -, and cheb_order = 1 holds the SUM of its dense supports."""
         self._need_prepared()
         lay = (C.c_int64 * 4)()
         _lib.check(self.lib.matgcn_supports_layout(C.byref(self.dims), C.byref(lay)), "matgcn_supports_layout")
         off, ld, npad, ks = (int(v) for v in lay)
-        s, n = self.spec, self.spec.nodes
-        st = self.prepared[off:off + npad * ld].view(npad, ld) if ks > 0 else None
-        per = s.cheb_k - 1
-        adp = 0 if s.adpadj == "none" else 1
-        out, kd = [], 0
-        for f in range(s.n_first):
-            diag = f >= adp and (s.diag_static_mask >> (f - adp)) & 1
-            if diag:
-                dvec = torch.diagonal(self._static[f - adp]).double()
-                t0, t1 = torch.ones_like(dvec), dvec
-                for j in range(per):
-                    out.append(torch.diag(t1).float())
-                    t0, t1 = t1, 2 * dvec * t1 - t0
-            else:
-                for j in range(per):
-                    out.append(st[:n, kd * npad:kd * npad + n].t())
-                    kd += 1
-        assert kd == ks
-        return torch.stack([o.to(self.device) for o in out], 0).contiguous()
+        n = self.spec.nodes
+        if ks == 0:
+            return torch.empty(0, n, n, dtype=torch.float32, device=self.device)
+        st = self.prepared[off:off + npad * ld].view(npad, ld)
+        return torch.stack([st[:n, k * npad:k * npad + n].t() for k in range(ks)], 0).contiguous()
+
+    def node_weights(self, layer: int, part: int) -> torch.Tensor:
+        """(N, 1 + Ks, 64, O): the recurrent (hidden-channel) rows of the node-adaptive weights of
+        agru_cells[layer].gate (part 0, O = 128) / .update (part 1, O = 64), decoded from the MFMA-fragment-ordered
+        stream matgcn_prepare wrote into `prepared` (tests: softmax(weights_g) and the diagonal-support fold included)."""
+        self._need_prepared()
+        lay = (C.c_int64 * 4)()
+        _lib.check(self.lib.matgcn_weights_layout(C.byref(self.dims), layer, part, C.byref(lay)),
+                   "matgcn_weights_layout")
+        off, stride, groups, ot = (int(v) for v in lay)
+        n, o_dim = self.spec.nodes, ot * 16
+        idx = torch.arange(n, device=self.device)[:, None] * stride + off + \
+            torch.arange(groups * ot * 256, device=self.device)[None, :]
+        frag = self.prepared[idx].view(n, groups, ot, 4, 16, 4)      # [n][g][ct][kq][j][s]
+        # row kk = 16 g + 4 kq + s, column o = 16 ct + j
+        w = frag.permute(0, 1, 3, 5, 2, 4).reshape(n, groups * 16, o_dim)
+        return w.view(n, groups // 4, 64, o_dim).contiguous()

@@ -57,7 +57,13 @@ def run_case(case):
     out["param_checksum"] = np.float64(sum(float(np.abs(v.astype(np.float64)).sum()) for v in state.values()))
 
     # static supports as the reference stores them (plain attributes, MultiATGCN.py:264-283)
-    out["static_supports"] = np.stack([s[1].numpy() for s in model.supports], 0)
+    statics = np.stack([s[1].numpy() for s in model.supports], 0)
+    if case.get("big", False):
+        # 3 x N x N does not fit a fixture at N = 4096: every BIG_SUB-th element + per-support [sum, sum |.|]
+        out["static_sub"] = statics.reshape(statics.shape[0], -1)[:, ::BIG_SUB].copy()
+        out["static_sums"] = np.stack([statics.astype(np.float64).sum((1, 2)), np.abs(statics.astype(np.float64)).sum((1, 2))], 1)
+    else:
+        out["static_supports"] = statics
 
     # --- capture the support stack of every AGCN and the fused encoder input
     captured = {"stacks": [], "x0": None}
@@ -123,6 +129,8 @@ def run_case(case):
     return out
 
 
+BIG_SUB = 4099   # prime stride of the static-support subsample of the N = 4096 case
+
 CASES = []
 _modes = [("multi", "unidirection"), ("multi", "bidirection"), ("multi", "none"),
           ("od", "unidirection"), ("od", "none"), ("identity", "none"), ("dist", "none"),
@@ -131,6 +139,12 @@ for (adjt, adp) in _modes:
     for cheb in (2, 3):
         CASES.append(dict(name="tiny_%s_%s_c%d" % (adjt, adp[:3], cheb), nodes=21, batch=2, out=3,
                           feat=2, adjtype=adjt, adpadj=adp, cheb=cheb, seed=10, stages=True))
+# cheb_order = 1, the first value of the sweep the reference ships enabled (run_model_parameter.py:13): ONE weight
+# entry broadcast by einsum over the stack [I, S_1, S_2, ..] (MultiATGCN.py:65-70,94-108)
+for (adjt, adp) in [("multi", "unidirection"), ("multi", "bidirection"), ("multi", "none"), ("od", "unidirection"),
+                    ("od", "none"), ("identity", "none")]:
+    CASES.append(dict(name="tiny_%s_%s_c1" % (adjt, adp[:3]), nodes=21, batch=2, out=3, feat=2, adjtype=adjt,
+                      adpadj=adp, cheb=1, seed=10, stages=True))
 CASES.append(dict(name="tiny_multi_uni_out12", nodes=21, batch=3, out=12, feat=2, adjtype="multi",
                   adpadj="unidirection", cheb=2, seed=100, stages=True))
 CASES.append(dict(name="tiny_multi_uni_dyn7", nodes=19, batch=2, out=6, feat=7, adjtype="multi",
@@ -144,6 +158,11 @@ CASES.append(dict(name="bm403_out24", nodes=403, batch=4, out=24, feat=2, adjtyp
 CASES.append(dict(name="bm403_out24_bi", nodes=403, batch=2, out=24, feat=2, adjtype="multi",
                   adpadj="bidirection", cheb=2, seed=100, city="BM"))
 
+
+# BASELINE config 5's graph: synthetic 4096 nodes, in 24 -> out 24 (per-GPU share of the batch cut to 2 so that the
+# reference finishes in minutes on CPU); prediction, loss and MAE@k only, static supports as a subsample
+CASES.append(dict(name="synth4096_out24", nodes=4096, batch=2, out=24, feat=2, adjtype="multi",
+                  adpadj="unidirection", cheb=2, seed=1000, city="BM", big=True))
 
 # ablation switches of the reference (run_model_parameter.py:6-15), final outputs only
 for nm, flags in (("gcnoff", {"gcn_off": True}), ("fnnoff", {"fnn_off": True}),

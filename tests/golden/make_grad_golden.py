@@ -19,7 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (imports the reference)
 
-NAMES = ["tiny_multi_uni_c2", "tiny_multi_bid_c2", "tiny_od_non_c2", "tiny_multi_uni_dyn7"]
+NAMES = ["tiny_multi_uni_c2", "tiny_multi_bid_c2", "tiny_od_non_c2", "tiny_multi_uni_dyn7", "tiny_multi_uni_c1",
+         "tiny_identity_non_c1"]
 SUB = 17
 
 
@@ -66,7 +67,10 @@ def run(case):
 
 def main():
     cases = {c["name"]: c for c in mg.CASES}
+    only = set(sys.argv[1:])
     for name in NAMES:
+        if only and name not in only:
+            continue
         res = run(cases[name])
         np.savez_compressed(os.path.join(HERE, "grad_%s.npz" % name), **res)
         print("%-24s loss %.6f  |d_out|max %.3e  %d gradients" % (

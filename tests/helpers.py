@@ -12,7 +12,8 @@ with open(os.path.join(GOLDEN_DIR, "index.json")) as fh:
     INDEX = json.load(fh)
 
 TINY = sorted(k for k in INDEX if k.startswith("tiny_"))
-FULL = sorted(k for k in INDEX if not k.startswith("tiny_"))
+BIG = sorted(k for k in INDEX if INDEX[k].get("big"))      # N = 4096: prediction only, static supports subsampled
+FULL = sorted(k for k in INDEX if not k.startswith("tiny_") and k not in BIG)
 
 
 class Case:

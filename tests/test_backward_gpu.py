@@ -308,6 +308,10 @@ def test_full_size_directional_derivative(lib_built):
     (16, 70, 2, {}), (32, 5, 2, {}), (21, 3, 1, {}), (21, 3, 3, {}), (16, 2, 4, {}), (21, 1, 2, {}),
     (21, 2, 3, {"gcn_off": True}), (21, 2, 3, {"fnn_off": True}), (21, 2, 1, {"gcn_off": True, "fnn_off": True}),
     (19, 2, 3, {"cheb_order": 3}),
+    # cheb_order = 1 (run_model_parameter.py:13): one weight entry over I + sum of the supports (MultiATGCN.py:94-108)
+    (21, 2, 3, {"cheb_order": 1}), (16, 3, 1, {"cheb_order": 1, "adjtype": "od", "adpadj": "none"}),
+    (21, 2, 2, {"cheb_order": 1, "adjtype": "identity", "adpadj": "none"}),
+    (19, 5, 2, {"cheb_order": 1, "adjtype": "multi", "adpadj": "bidirection"}),
     (21, 2, 3, {"adjtype": "od", "adpadj": "bidirection"}), (21, 2, 1, {"adjtype": "dist", "adpadj": "none"}),
     (16, 3, 3, {"adjtype": "identity", "adpadj": "none", "cheb_order": 3}), (21, 2, 3, {"adjtype": "multi", "adpadj": "none"}),
     (21, 2, 3, {"adjtype": "cosine", "adpadj": "unidirection", "cheb_order": 3}),

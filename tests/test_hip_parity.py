@@ -31,25 +31,90 @@ def _path(c, lib_built, fold=True):
     return hp, dev
 
 
-def _unscaled_stack(c, which):
-    """reference stack (K,N,N) with softmax(weights_g) divided out -> the raw non-identity supports"""
+def _unscaled_stack_all(c, which):
+    """reference stack (K,N,N), identity included, with softmax(weights_g) divided out -> the raw supports"""
     stack = c.gold["stack_l0_%s" % which].astype(np.float64)
     if c.adjtype == "multi":
         g = c.state["encoder.agru_cells.0.%s.weights_g" % which].reshape(-1).astype(np.float64)
         g = np.exp(g - g.max())
         g /= g.sum()
         stack = stack / g[:, None, None]
-    return stack[1:]
+    return stack
 
 
+def _first_order(c, spec):
+    """[(is_diagonal, [reference stack indices of its Chebyshev orders])] per first-order support, in stack order
+    (MultiATGCN.py:94-100: [I, orders of S_1.., orders of S_2.., ..]; cheb_order = 1 still appends S itself)"""
+    per = max(1, c.cheb - 1)
+    adp = 0 if c.adpadj == "none" else 1
+    out = []
+    for f in range(spec.n_first):
+        diag = f >= adp and bool((spec.diag_static_mask >> (f - adp)) & 1)
+        out.append((diag, [1 + f * per + j for j in range(per)]))
+    return out
+
+
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("name", TINY)
-def test_support_stack(name, lib_built):
+def test_support_stack(name, fold, lib_built):
+    """the DENSE slots the device built (adaptive adjacency softmax(relu(.)), static Laplacians, Chebyshev orders;
+    cheb_order = 1: their sum) against the reference's stack; folded diagonal supports are not in the stack - they are
+    checked where they went, in test_prepared_weights_carry_gains_and_folded_diagonals"""
     c = Case(name)
-    hp, _ = _path(c, lib_built)
+    hp, _ = _path(c, lib_built, fold)
     got = hp.supports().cpu().numpy()
-    want = _unscaled_stack(c, "gate")
-    assert got.shape == want.shape
-    assert max_norm_err(got, want) <= STAGE_TOL
+    ref = _unscaled_stack_all(c, "gate")
+    dense = [idx for diag, idx in _first_order(c, hp.spec) if not diag]
+    if c.cheb == 1:
+        want = [sum(ref[i[0]] for i in dense)] if dense else []
+    else:
+        want = [ref[i] for idx in dense for i in idx]
+    assert got.shape[0] == len(want)
+    if want:
+        assert max_norm_err(got, np.stack(want, 0)) <= STAGE_TOL
+
+
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("name", TINY)
+def test_prepared_weights_carry_gains_and_folded_diagonals(name, fold, lib_built):
+    """Read the node-adaptive weight streams back from `prepared` (what the node kernels really contract with) and
+    compare with einsum('nd,dkio->nkio') of the reference (MultiATGCN.py:104) in fp64, with softmax(weights_g) folded in
+    (:102-103) and every diagonal support folded into the identity slot scaled by its Chebyshev value t_j(s_n)."""
+    c = Case(name)
+    hp, _ = _path(c, lib_built, fold)
+    spec = hp.spec
+    adp = 0 if c.adpadj == "none" else 1
+    firsts = _first_order(c, spec)
+    emb = c.state["node_emb"].astype(np.float64)
+    for layer in range(2):
+        cin = c.feat if layer == 0 else 64
+        for part, nm in enumerate(("gate", "update")):
+            pre = "encoder.agru_cells.%d.%s." % (layer, nm)
+            pool = c.state[pre + "weights_pool"].astype(np.float64)[:, :, cin:cin + 64, :]      # hidden-channel rows
+            w = np.einsum("nd,dkio->nkio", emb, pool)
+            kt = pool.shape[1]
+            gain = np.ones(kt)
+            if c.adjtype == "multi":
+                wg = c.state[pre + "weights_g"].reshape(-1).astype(np.float64)
+                gain = np.exp(wg - wg.max()) / np.exp(wg - wg.max()).sum()
+            pk = (lambda k: 0) if c.cheb == 1 else (lambda k: k)     # cheb_order = 1: every entry reads pool index 0
+            ident = gain[0] * w[:, 0]
+            slots = []
+            for f, (diag, idx) in enumerate(firsts):
+                if diag:
+                    sn = np.diagonal(c.gold["static_supports"][f - adp]).astype(np.float64)
+                    t0, t1 = np.ones_like(sn), sn
+                    for k in idx:
+                        ident = ident + gain[pk(k)] * t1[:, None, None] * w[:, pk(k)]
+                        t0, t1 = t1, 2 * sn * t1 - t0
+                elif c.cheb > 1:
+                    slots += [gain[k] * w[:, k] for k in idx]
+            if c.cheb == 1 and any(not d for d, _ in firsts):
+                slots = [gain[0] * w[:, 0]]
+            want = np.stack([ident] + slots, 1)
+            got = hp.node_weights(layer, part).cpu().numpy()
+            assert got.shape == want.shape, (layer, nm)
+            assert max_norm_err(got, want) <= STAGE_TOL, (layer, nm)
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -181,3 +246,71 @@ def test_full_size_batch_properties(lib_built):
     x2[1:] = torch.roll(x2[1:], 1, dims=0)          # sample 0 keeps its place, the rest of the batch changes
     assert torch.equal(hp.forward(x2)[0], a[0])
     assert torch.isfinite(a).all()
+
+
+# ---- BASELINE config 5's graph: synthetic 4096 nodes (reference-generated fixture synth4096_out24) ----------------
+def _big_path(c, batch, lib_built):
+    """N = 4096: the static supports come from the plugin's own host graph prep (3 x N x N is no fixture); the test
+    first pins that prep to the reference's subsample, then hands it to the HIP path"""
+    from multistgraph_amd import graph_prep
+    from multistgraph_amd.ops import HotPath, diagonal_mask, spec_from_config
+    mats = np.stack(graph_prep.build_static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], None,
+                                                     c.adjtype), 0)
+    sub = mats.reshape(mats.shape[0], -1)[:, ::4099]
+    assert sub.shape == c.gold["static_sub"].shape
+    assert np.abs(sub - c.gold["static_sub"]).max() <= 1e-6
+    sums = np.stack([mats.astype(np.float64).sum((1, 2)), np.abs(mats.astype(np.float64)).sum((1, 2))], 1)
+    assert np.abs(sums - c.gold["static_sums"]).max() <= 1e-5 * np.abs(c.gold["static_sums"]).max()
+    dev = torch.device("cuda:0")
+    st = torch.from_numpy(mats).to(dev)
+    cfg = dict(c.config(), batch_size=batch)
+    spec = spec_from_config(cfg, c.data_feature, c.n, 20, 3, diagonal_mask(torch.from_numpy(mats)))
+    hp = HotPath(spec, batch, dev)
+    state = {k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}
+    hp.bind(state, st)
+    return hp, dev, state, mats
+
+
+def test_forward_synth4096(lib_built):
+    """BASELINE config 5 (4096-node graph, in 24 -> out 24) against the reference's own prediction, loss and MAE@k
+    at B = 2: Np = 4096, St = [4096][12288], 192 row tiles per column tile, every 32-bit offset at its largest"""
+    from multistgraph_amd.ops import masked_mae_device
+    c = Case("synth4096_out24")
+    assert c.checksums_ok()
+    hp, dev, _, _ = _big_path(c, c.b, lib_built)
+    got = hp.forward(torch.from_numpy(c.x).to(dev))
+    assert got.shape == c.gold["pred"].shape
+    assert max_norm_err(got.cpu().numpy(), c.gold["pred"]) <= E2E_TOL
+    res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0, null_val=0.0).cpu().numpy()
+    assert abs(res[0] - float(c.gold["loss"])) <= 1e-4 * abs(float(c.gold["loss"]))
+    res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0).cpu().numpy()
+    assert np.abs(res[1:] - c.gold["mae_at"]).max() <= 1e-4 * np.abs(c.gold["mae_at"]).max()
+
+
+def test_backward_synth4096_vs_fp64_oracle(lib_built):
+    """one gradient check at N = 4096, B = 1: matgcn_forward_train + matgcn_backward against fp64 autograd through the
+    oracle (hoisted order) on the GPU box's host cores"""
+    from oracle import matgcn_oracle as orc
+    c = Case("synth4096_out24")
+    hp, dev, state, mats = _big_path(c, 1, lib_built)
+    x_np = c.x[:1].copy()
+    rng = np.random.default_rng(31)
+    d_out = rng.standard_normal((1, c.out, c.n, 1)).astype(np.float32)
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in c.state.items()}
+    y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [torch.from_numpy(m).double() for m in mats],
+                    c.oracle_cfg(), faithful=False)
+    (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
+    x = torch.from_numpy(x_np).to(dev)
+    got_y = hp.forward_train(x)
+    assert max_norm_err(got_y.cpu().numpy(), y.detach().numpy()) <= E2E_TOL
+    assert max_norm_err(got_y.cpu().numpy(), c.gold["pred"][:1]) <= E2E_TOL     # batch items are independent
+    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state)
+    bad = {}
+    for k, v in p.items():
+        w = v.grad.numpy() if v.grad is not None else np.zeros(v.shape)
+        if np.abs(w).max() == 0.0:
+            if float(grads[k].abs().max()) > 1e-6:
+                bad[k] = "expected zero"
+        elif max_norm_err(grads[k].cpu().numpy(), w) > 1e-4:
+            bad[k] = max_norm_err(grads[k].cpu().numpy(), w)
+    assert not bad, bad

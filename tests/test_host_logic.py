@@ -87,7 +87,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym)
-    assert lib.matgcn_abi_version() == 8
+    assert lib.matgcn_abi_version() == _lib.ABI_VERSION == 9
     assert lib.matgcn_error_string(-3) == b"configuration not supported by this build"
 
 
