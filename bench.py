@@ -21,8 +21,14 @@ Rank 0 prints ONE JSON line.  Two extra objects:
                  the headline figure comes from instrumented forwards with the wavefront switched off
                  (matgcn_set_wavefront(0): same kernels, one stream - the launch duration is the kernel's
                  own), and `in_wavefront` repeats it for an instrumented forward of the timed configuration.
-                 `traffic` is the HBM traffic per launch from the rocprofv3 PMC pass committed under
-                 profiles/ (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE), or null.
+                 `traffic` / `mfma_util_pmc` are the HBM traffic per launch (FETCH_SIZE doubled as the gfx950
+                 guide prescribes, + WRITE_SIZE) and the MFMA-busy fraction from the rocprofv3 PMC passes
+                 committed under profiles/ (tools/profile_r02.sh) - replayed ONLY when they were collected on the
+                 build that is running (`build_id`, a hash of the library's sources), else null.
+                 `node_kernels` lists the next-largest kernels (k_gate16, k_update16, k_px16) the same way.
+  median       - the §8(d) protocol: 20 warm-up + 100 forwards, each bracketed by HIP events on the caller's
+                 stream (the internal streams join back into it before the forward's last kernel); median,
+                 p10, p90.  `value` stays the driver's contract (K steps between two barriers).
   cpu_baseline - the CPU oracle in its reference-faithful order (oracle/, kind "port"), timed on this
                  host's cores on the same workload (rank 0, N=1 only).
 """
@@ -76,6 +82,37 @@ def executed_flops_per_unit(n, ks, c0=2, h=64, out=24, steps=24):
 
 def algorithmic_bytes_per_unit(c0=2, h=64, elem=4):
     return elem * ((2 * c0 + 7 * h) + (2 * h + 7 * h))
+
+
+def step_kernel_models(n, npad, b, ks, h=64):
+    """FLOPs and algorithmic HBM bytes of one launch of every per-step kernel (a layer >= 1 launch: PX carries the x
+    part): each operand counted once - weights streamed once per node, rows read / written once."""
+    rows, kt = n * b, (1 + ks) * h
+    return {
+        "k_mix": dict(flops=2.0 * ks * n * n * b * h, bytes=4.0 * (ks * npad * npad + rows * h + ks * rows * h)),
+        "k_gate": dict(flops=2.0 * rows * kt * 2 * h,
+                       bytes=4.0 * (n * kt * 2 * h + ks * rows * h + rows * h + rows * 2 * h + rows * 2 * h)),
+        "k_update": dict(flops=2.0 * rows * kt * h + 2.0 * rows * 2 * h * 3 * h,
+                         bytes=4.0 * (n * kt * h + ks * rows * h + rows * h + rows * h + rows * h + rows * h + rows * h
+                                      + 2 * rows * h)),
+        "k_px": dict(flops=2.0 * rows * kt * 3 * h, bytes=4.0 * (n * kt * 3 * h + ks * rows * h + rows * h + rows * 3 * h)),
+    }
+
+
+PMC_KERNEL_NAMES = {"k_mix": "k_mix<1>", "k_gate": "k_gate16<false>", "k_update": "k_update16<1, false>", "k_px": "k_px16"}
+
+
+def load_pmc(build_id):
+    """profiles/r02_pmc_kernels.json (tools/profile_r02.sh + tools/summarise_pmc.py) when it belongs to this build"""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
+    if not os.path.exists(path):
+        return None, "no PMC summary under profiles/"
+    with open(path) as fh:
+        doc = json.load(fh)
+    if doc.get("build_id") != build_id:
+        return None, "profiles/r02_pmc_kernels.json was collected on build %s, this is build %s: not replayed" % (
+            doc.get("build_id"), build_id)
+    return doc, "profiles/r02_pmc_kernels.json (build %s): %s" % (build_id, doc.get("method", "").split("\n")[0])
 
 
 def build_model(w, device, seed):
@@ -184,7 +221,11 @@ def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None):
         loss.backward()
         ev[2].record()
         if world > 1:
-            sharding.flat_allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
+            bucket = model.gradient_bucket()     # the gradients ARE views of one flat buffer: one collective, no copy
+            if bucket is not None:
+                sharding.bucket_allreduce_mean_(bucket)
+            else:
+                sharding.flat_allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
         ev[3].record()
         opt.step()
         ev[4].record()
@@ -204,6 +245,7 @@ def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None):
                    "(+ one flat-bucket gradient all-reduce when n_gpus > 1) + torch Adam; dropout p=0.1 on"}
     if world > 1:
         out["grad_bucket_mb"] = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4 / 1e6
+        out["grad_bucket_is_one_buffer"] = model.gradient_bucket() is not None
         out["replicas_in_sync"] = sharding.replicas_in_sync(model.parameters(), device=device)
     return out
 
@@ -219,6 +261,9 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing (N=1 only)")
     ap.add_argument("--cache-prepared", action="store_true",
                     help="keep matgcn_prepare out of the timed steps (inference with frozen weights)")
+    ap.add_argument("--median", type=int, default=100,
+                    help="forwards of the HIP-event-timed median protocol (SURVEY.md 8d; 0 = skip)")
+    ap.add_argument("--median-warmup", type=int, default=20)
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the timed steps too with the layer wavefront off (one stream): the configuration the "
                          "kernel roofline is measured in; used for the rocprofv3 profile that must agree with it")
@@ -291,6 +336,24 @@ def main():
             sync_all()
             frozen_elapsed = time.perf_counter() - t1
         model.cache_prepared = False
+    # SURVEY.md 8d protocol: >= 20 warm-up, >= 100 forwards, every one between two HIP events, median
+    median = None
+    if args.median > 0:
+        with torch.no_grad():
+            for _ in range(args.median_warmup):
+                model.predict(batch)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.median)]
+            for e0, e1 in evs:
+                e0.record()
+                pred = model.predict(batch)
+                e1.record()
+            torch.cuda.synchronize()
+        ts_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        med = statistics.median(ts_ms)
+        median = {"forwards": args.median, "warmup": args.median_warmup, "median_ms": med,
+                  "p10_ms": ts_ms[len(ts_ms) // 10], "p90_ms": ts_ms[(len(ts_ms) * 9) // 10], "min_ms": ts_ms[0],
+                  "node_steps_per_s_rank0": w["batch"] * 24 * w["nodes"] / (med * 1e-3),
+                  "note": "each forward bracketed by HIP events on the caller's stream, rank 0"}
     units_local = w["batch"] * 24 * w["nodes"] * args.steps
     if distributed:
         from multistgraph_amd import sharding
@@ -312,6 +375,7 @@ def main():
         ks = (spec.n_first - n_diag) * (spec.cheb_k - 1)
         mix_flops = 2.0 * ks * n * n * b * h                       # executed = algorithmic of the dense slots, unpadded
 
+        build_id = mbuild.source_id()
         serial = in_situ_kernel_times(model, batch, wavefront=False, forwards=2)
         conc = in_situ_kernel_times(model, batch, wavefront=True, forwards=1)
         step_mix = serial.get("k_mix", [])       # k_mix<1>: the 96 per-step launches of each forward
@@ -319,43 +383,67 @@ def main():
         achieved = mix_flops / (mix_ms * 1e-3) / 1e12
         conc_mix = conc.get("k_mix", [])
         conc_ms = statistics.mean(conc_mix) if conc_mix else float("nan")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_k_mix.json")
-        if os.path.exists(tpath) and args.workload == "bm403" and w["batch"] == 64:
-            with open(tpath) as fh:
-                traffic = json.load(fh)
-        mfma_pmc = None
-        mpath = os.path.join(ROOT, "profiles", "r01_v7_mfma_util.json")
-        if os.path.exists(mpath) and args.workload == "bm403" and w["batch"] == 64:
-            with open(mpath) as fh:
-                mfma_pmc = json.load(fh)["kernels"].get("void k_mix<1>(MixArgs)")
+        pmc, pmc_note = (None, "PMC summary exists for bm403 B=64 only")
+        if args.workload == "bm403" and w["batch"] == 64:
+            pmc, pmc_note = load_pmc(build_id)
+
+        def pmc_of(kind):
+            if pmc is None:
+                return None
+            for name, v in pmc["kernels"].items():
+                if PMC_KERNEL_NAMES[kind] in name:
+                    return v
+            return None
+
+        models = step_kernel_models(n, (n + 15) // 16 * 16, b, ks)
+        node_kernels = {}
+        for kind in ("k_gate", "k_update", "k_px"):
+            ms_list = serial.get(kind, [])
+            if not ms_list:
+                continue
+            t = statistics.mean(ms_list) * 1e-3
+            pk = pmc_of(kind)
+            node_kernels[PMC_KERNEL_NAMES[kind]] = dict(
+                launches=len(ms_list), avg_launch_ms=t * 1e3, flops_per_launch=models[kind]["flops"],
+                algorithmic_bytes_per_launch=models[kind]["bytes"], achieved_tflops=models[kind]["flops"] / t / 1e12,
+                frac_mfma=models[kind]["flops"] / t / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                achieved_algorithmic_tbs=models[kind]["bytes"] / t / 1e12,
+                traffic=pk and pk["hbm_bytes_per_launch"],
+                achieved_traffic_tbs=pk and pk["hbm_bytes_per_launch"] / t / 1e12,
+                frac_hbm=pk and pk["hbm_bytes_per_launch"] / t / 1e12 / PEAK_HBM_TBS,
+                mfma_util_pmc=pk and pk["mfma_util"])
+        mix_pmc = pmc_of("k_mix")
         times = conc
+        exec_unit = executed_flops_per_unit(w["nodes"], ks, out=w["out"])
+        exec_tflops = exec_unit * w["batch"] * 24 * w["nodes"] / (ms_per_step * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel="k_mix<1>", achieved=achieved, peak=PEAK_MFMA_F32_TFLOPS,
                         unit="TFLOP/s", frac=achieved / PEAK_MFMA_F32_TFLOPS,
-                        traffic=(traffic or {}).get("hbm_bytes_per_launch"),
-                        traffic_detail=traffic,
-                        mfma_util_pmc=mfma_pmc and dict(mfma_pmc, source="profiles/r01_v7_mfma_util.json: rocprofv3 --pmc "
-                                                        "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), "
-                                                        "tools/pmc_mfma.sh"),
+                        traffic=mix_pmc and mix_pmc["hbm_bytes_per_launch"],
+                        traffic_detail=mix_pmc and dict(mix_pmc, algorithmic_bytes_per_launch=models["k_mix"]["bytes"]),
+                        mfma_util_pmc=mix_pmc and mix_pmc["mfma_util"],
+                        pmc_source=pmc_note,
                         launches=len(step_mix), avg_launch_ms=mix_ms,
                         flops_per_launch=mix_flops,
                         measured="HIP events around each launch, wavefront off (kernel alone on the chip)",
                         in_wavefront=dict(avg_launch_ms=conc_ms, launches=len(conc_mix),
                                           note="the per-step k_mix<1> launches of one forward of the timed configuration; "
                                                "a launch shares the chip with the other layer's chain"),
+                        node_kernels=node_kernels,
                         serial_kernel_ms_per_forward={k: round(sum(v) / 2, 4) for k, v in serial.items()},
                         dense_supports_mixed=ks, supports_folded_into_weights=n_diag * (spec.cheb_k - 1),
-                        whole_forward=dict(algorithmic_tflops=fwd_tflops,
-                                           frac_mfma=fwd_tflops / PEAK_MFMA_F32_TFLOPS,
-                                           executed_tflops=fwd_tflops * executed_flops_per_unit(
-                                               w["nodes"], ks, out=w["out"]) / flops_unit,
-                                           note="algorithmic = SURVEY section 8d formula (all K-1 supports dense, x columns "
-                                                "mixed in both AGCNs of every layer); executed = what the kernels multiply: "
-                                                "dense supports only, x columns mixed once per layer and, for layers >= 1, "
-                                                "shared with the recurrent mix of the layer below",
+                        whole_forward=dict(executed_tflops=exec_tflops, frac_mfma=exec_tflops / PEAK_MFMA_F32_TFLOPS,
+                                           executed_flops_per_unit=exec_unit,
+                                           note="executed = what the kernels multiply: dense supports only (diagonal ones "
+                                                "are folded into the weights), x columns mixed once per layer and, for "
+                                                "layers >= 1, shared with the recurrent mix of the layer below; frac_mfma "
+                                                "= executed / the dense fp32 MFMA peak",
+                                           survey_formula_tflops=fwd_tflops, survey_formula_flops_per_unit=flops_unit,
+                                           survey_formula_note="SURVEY section 8d formula / time: counts all K-1 supports "
+                                                               "as dense and the x columns in both AGCNs of every layer, "
+                                                               "i.e. FLOPs these kernels no longer execute - NOT a "
+                                                               "utilisation figure",
                                            algorithmic_gbs=algorithmic_bytes_per_unit() * units_per_step / world /
-                                           (ms_per_step * 1e-3) / 1e9,
-                                           flops_per_unit=flops_unit),
+                                           (ms_per_step * 1e-3) / 1e9),
                         kernel_ms_per_forward={k: round(sum(v), 4) for k, v in times.items()})
         ytrue = batch["y"][..., 0:1].clone()
         from multistgraph_amd.model import masked_mae
@@ -371,8 +459,11 @@ def main():
                        "prepare_in_timed_region": not args.cache_prepared,
                        "layer_wavefront_streams": not args.serial_streams},
             "mae_at_12": mae12,
+            "build_id": build_id,
             "roofline": roofline,
         }
+        if median is not None:
+            result["median"] = median
         if frozen_elapsed is not None:
             result["frozen_weights"] = {
                 "ms_per_step": frozen_elapsed / args.steps * 1e3,
@@ -390,10 +481,12 @@ def main():
             if not args.no_cpu_baseline and args.workload != "synth4096":
                 cpu_train = cpu_train_baseline(w, x_np, y_np, dict(model.named_parameters()), df)   # before the weights move
             ts = train_step_times(model, batch, w)
-            # every forward GEMM has two backward GEMMs (input gradient, weight gradient): backward ~ 2x forward FLOPs
-            bwd_flops = 2.0 * flops_unit * w["batch"] * 24 * w["nodes"]
-            ts["backward_algorithmic_tflops"] = bwd_flops / (ts["backward_ms"] * 1e-3) / 1e12
-            ts["backward_frac_mfma"] = ts["backward_algorithmic_tflops"] / PEAK_MFMA_F32_TFLOPS
+            # every forward GEMM has two backward GEMMs (input gradient, weight gradient): the backward executes ~2x the
+            # forward's EXECUTED FLOPs (dense supports only, shared mixes) - not 2x the SURVEY formula
+            bwd_flops = 2.0 * exec_unit * w["batch"] * 24 * w["nodes"]
+            ts["backward_executed_tflops"] = bwd_flops / (ts["backward_ms"] * 1e-3) / 1e12
+            ts["backward_frac_mfma"] = ts["backward_executed_tflops"] / PEAK_MFMA_F32_TFLOPS
+            ts["backward_flops_note"] = "2 x the forward's executed FLOPs per node-step (%.0f) / backward time" % exec_unit
             if cpu_train is not None:
                 ts["cpu_baseline"] = cpu_train
                 ts["gpu_over_cpu"] = ts["node_steps_per_s"] / cpu_train["value"]

@@ -136,10 +136,13 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
                    size_t prepared_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the path ------------------------------------------------------------------------------
- * MultiATGCN.forward / predict (MultiATGCN.py:363-420, eval mode, zero initial state):
- * X (B, x_steps, N, F) -> out (B, output_window, N, output_dim). */
+ * MultiATGCN.forward / predict (MultiATGCN.py:363-420, eval mode):
+ * X (B, x_steps, N, F) -> out (B, output_window, N, output_dim).
+ * h0: initial state of the encoder, (L, B, N, H) device, or NULL for the zero state of init_hidden (:214-218, :405).
+ * With static features the reference starts every layer and sample from static_initial_gru(static @ v) (:406-409):
+ * that (N, H) embedding is host-side torch (a PCA and one nn.Linear), expanded to (L, B, N, H) by the caller. */
 int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
-                   const float* X, float* out, void* workspace, size_t workspace_bytes,
+                   const float* X, const float* h0, float* out, void* workspace, size_t workspace_bytes,
                    void* stream);
 
 /* The same forward fed from the raw series instead of materialised windows (replaces the window build of
@@ -150,8 +153,17 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
  * Row s of sample b is series[label_start[b] + rel_steps[s]]; the caller guarantees they are in range. */
 int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                           const float* series, int64_t series_steps, const int32_t* label_start,
-                          const int32_t* rel_steps, float* out, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          const int32_t* rel_steps, const float* h0, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* The batch as B label starts into the device-resident raw series instead of materialised windows: what
+ * matgcn_forward_series takes as separate arguments, as one descriptor for the training entry points. */
+typedef struct matgcn_series {
+  const float* series;        /* (series_steps, N, F) device */
+  int64_t series_steps;
+  const int32_t* label_start; /* (B) device: first target step of every sample */
+  const int32_t* rel_steps;   /* (x_steps) HOST: offset of every window row relative to its label start */
+} matgcn_series;
 
 /* ---- the pieces (same kernels, exposed for parity tests against the reference's modules) ----
  * temporal-head fusion + channel concat (MultiATGCN.py:365-402): X -> x0 (B, T, N, feat_in) */
@@ -194,18 +206,22 @@ int matgcn_output_head(const matgcn_dims* dims, const matgcn_params* params, con
  *   result[0]     = sum(|p-l|*mask) / sum(mask)              (the masked-MAE loss over all horizons)
  *   result[1 + k] = the same restricted to horizon k          (MAE@k+1)
  * pred (B, out, N, od) contiguous; y (B, y_steps >= out, N, y_feat), channels y_start .. y_start+od-1.
+ * label_start != NULL (device, B int32): `y` is the raw series (y_steps, N, y_feat) instead and the label rows of
+ * sample b are y[label_start[b] + o], o < out - the targets MTHDataset._generate_input_data materialises
+ * (mth_dataset.py:110-160) are gathered here, on the device.
  * partials: caller-owned device scratch of 2*B*out + 1 floats (the last one keeps sum(mask) for the gradient);
  * result: device, 1+out floats.  Two launches, fixed summation order (no atomics): results are run-to-run identical. */
-int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
-                      int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
-                      float* partials, float* result, void* stream);
+int matgcn_masked_mae(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps, int nodes,
+                      int out_dim, int y_steps, int y_feat, int y_start, float mean, float std, float null_val,
+                      float min_s, float* partials, float* result, void* stream);
 
 /* Gradient of result[0] (the calculate_loss value) w.r.t. pred, for the training step: d_pred (B, out, N, od) =
  * upstream[0] * std * sign(p - l) * mask / sum(mask), with `partials` as left by the matching matgcn_masked_mae call
  * and `upstream` the device scalar autograd hands down (d loss / d loss = 1 for a plain loss.backward()). */
-int matgcn_masked_mae_grad(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
-                           int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
-                           const float* partials, const float* upstream, float* d_pred, void* stream);
+int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps,
+                           int nodes, int out_dim, int y_steps, int y_feat, int y_start, float mean, float std,
+                           float null_val, float min_s, const float* partials, const float* upstream, float* d_pred,
+                           void* stream);
 
 /* ---- training step: forward that keeps activations + backward -----------
  * Replaces torch autograd through MultiATGCN.forward as driven by TrafficStateExecutor._train_epoch
@@ -213,7 +229,7 @@ int matgcn_masked_mae_grad(const float* pred, const float* y, int batch, int out
  * matgcn_grads mirrors matgcn_params field by field (same shapes); every non-NULL gradient is OVERWRITTEN.
  * node_emb may be NULL (node_specific_off freezes it); node_vec1/2 are required iff adp_mode == UNI.
  * `train` is one more caller-owned device buffer of matgcn_train_bytes(): forward_train saves z, r, hc of the
- * graph cell, z2, r2, hc2 of the residual cell and the graph-mixed rows of every (layer, step) into it, backward uses
+ * graph cell, z2, r2, hc2 of the residual cell, the initial state and the graph-mixed rows of every (layer, step) into it, backward uses
  * the rest as scratch.  matgcn_backward must see the SAME workspace and train buffers, untouched, that the matching
  * matgcn_forward_train call used (the sequences of every layer live in the workspace).
  * d_out (B, output_window, N, output_dim) is the gradient of the loss w.r.t. the forward's output.
@@ -251,12 +267,18 @@ typedef struct matgcn_grads {
 } matgcn_grads;
 
 int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes);
+/* src != NULL: the batch comes from the device-resident series (X is ignored and may be NULL), as in
+ * matgcn_forward_series; the matching matgcn_backward must get the same descriptor. */
 int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
-                         const float* X, const float* drop_mask, float* out, void* workspace,
-                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream);
+                         const float* X, const matgcn_series* src, const float* h0, const float* drop_mask, float* out,
+                         void* workspace, size_t workspace_bytes, void* train, size_t train_bytes, void* stream);
+/* h0: the pointer the matching matgcn_forward_train saw (NULL = zero initial state; the backward reads the padded copy
+ * forward_train kept in `train`, the pointer only says that there was one).  d_h0: (L, B, N, H) gradient of the loss
+ * w.r.t. the initial state, or NULL when the caller does not need it (it is overwritten, not accumulated). */
 int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                    const float* drop_mask, const float* d_out, const matgcn_grads* grads, void* workspace,
-                    size_t workspace_bytes, void* train, size_t train_bytes, void* stream);
+                    const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
+                    const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
+                    size_t train_bytes, void* stream);
 
 /* The one contraction kernel of the backward, exposed for its parity test: a strided, two-level-batched fp32
  * GEMM  C[b1][b2] (+)= alpha * sum_{k2,k} A[b1][b2][m][k2][k] B[b1][b2][k2][k][n].  desc (22 x int64, host):

@@ -46,6 +46,12 @@ class LinearParams(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class Series(C.Structure):
+    """matgcn_series: the batch as label starts into the device-resident raw series"""
+    _fields_ = [("series", C.c_void_p), ("series_steps", C.c_int64), ("label_start", C.c_void_p),
+                ("rel_steps", C.POINTER(C.c_int32))]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("node_emb", C.c_void_p), ("node_vec1", C.c_void_p), ("node_vec2", C.c_void_p),
@@ -67,9 +73,9 @@ _SIGNATURES = {
     "matgcn_supports_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_int64 * 4)]),
     "matgcn_weights_layout": (C.c_int, [C.POINTER(Dims), C.c_int, C.c_int, C.POINTER(C.c_int64 * 4)]),
     "matgcn_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_size_t, _P, C.c_size_t, _P]),
-    "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "matgcn_forward_series": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.c_int64, _P,
-                                        C.POINTER(C.c_int32), _P, _P, C.c_size_t, _P]),
+                                        C.POINTER(C.c_int32), _P, _P, _P, C.c_size_t, _P]),
     "matgcn_fuse_heads": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.c_size_t, _P]),
     "matgcn_agcn_gate_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
                                        C.c_size_t, _P]),
@@ -80,16 +86,16 @@ _SIGNATURES = {
     "matgcn_encoder_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, _P,
                                      C.c_size_t, _P]),
     "matgcn_output_head": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.c_size_t, _P]),
-    "matgcn_masked_mae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "matgcn_masked_mae": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
-    "matgcn_masked_mae_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "matgcn_masked_mae_grad": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
     "matgcn_train_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
-    "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, C.c_size_t, _P,
-                                       C.c_size_t, _P]),
+    "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.POINTER(Series), _P, _P, _P, _P,
+                                       C.c_size_t, _P, C.c_size_t, _P]),
     # matgcn_grads has the layout of matgcn_params (non-const pointers): the same ctypes struct serves both
-    "matgcn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, C.POINTER(Params), _P,
-                                  C.c_size_t, _P, C.c_size_t, _P]),
+    "matgcn_backward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.POINTER(Series), _P, _P, _P,
+                                  C.POINTER(Params), _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "matgcn_debug_gemm": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_float, C.c_float, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),

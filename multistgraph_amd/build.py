@@ -26,6 +26,16 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def source_id() -> str:
+    """12 hex digits over the library's sources: the build a measurement belongs to (bench line, PMC summaries)."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

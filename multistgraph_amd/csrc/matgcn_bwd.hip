@@ -58,6 +58,9 @@ struct Bwd {
   const float* dropMask;
   const matgcn_grads* g;
   float* tr;
+  const matgcn_series* src = nullptr;   // series mode: X rows are gathered from the raw series
+  bool hasH0 = false;     // the forward started from a caller-supplied state (its padded copy sits at tr + R.oH0)
+  float* dH0 = nullptr;   // (L, B, N, H) gradient w.r.t. that state, or null
 };
 
 // the stack entries whose weights come out of the pools: kept slots first, then the folded diagonal ones (which share
@@ -193,6 +196,7 @@ struct Pass {
 struct LayerBufs {
   int l, C, I, par;
   const float* seq;          // Seq_l
+  const float* h0;           // h_{-1} of the layer [B][Np][64], or null = zeros
   float* dSeqCur;            // gradient of Seq_l
   float* dXall;              // gradient of the layer's input sequence (dSeq of the layer below / dX0)
   float *DPU, *DPG, *DPU2, *DPG2, *DAg, *DAu, *DAx;
@@ -217,6 +221,7 @@ struct LayerBufs {
 #define LAYER_LOCALS(L)                                                                                            \
   [[maybe_unused]] const int l = (L).l, C = (L).C, I = (L).I, par = (L).par;                                        \
   [[maybe_unused]] const float* seq = (L).seq; [[maybe_unused]] float* dSeqCur = (L).dSeqCur;                       \
+  [[maybe_unused]] const float* h0 = (L).h0;                                                                        \
   [[maybe_unused]] float* dXall = (L).dXall;                                                                        \
   [[maybe_unused]] float *DPU = (L).DPU, *DPG = (L).DPG, *DPU2 = (L).DPU2, *DPG2 = (L).DPG2, *DAg = (L).DAg,        \
                          *DAu = (L).DAu, *DAx = (L).DAx;                                                            \
@@ -339,7 +344,7 @@ int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
       memset(&a, 0, sizeof(a));
       a.dense = 1;
       a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : carry[(t + 1) & 1];
-      a.hprev = t > 0 ? seq + at - slab : nullptr;
+      a.hprev = t > 0 ? seq + at - slab : h0;
       a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
       a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR;
       a.B = B; a.N = N; a.Np = Np; a.S = S;
@@ -365,8 +370,14 @@ int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
     } else {
       Xall = c.ws + P.oSeq[l - 1];
     }
+    if (b.dH0) {   // the carry left by step 0 is the gradient of the layer's initial state
+      hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, carry[0], nullptr, nullptr,
+                         b.dH0 + (size_t)l * B * N * H, B, N, Np, S);
+      CHECK_LAUNCH();
+    }
     float* Hprev = tr + R.oHprev[par]; float* Z2H = tr + R.oZ2HA[par];
-    RETURN_IF(zero_async(Hprev, slab, s));
+    if (h0) HIP_OK(hipMemcpyAsync(Hprev, h0, (size_t)slab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else RETURN_IF(zero_async(Hprev, slab, s));
     if (T > 1)
       HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t seqN = (size_t)T * slab;
@@ -409,7 +420,7 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     const size_t at = (size_t)t * slab;
     ChainArgs a;
     memset(&a, 0, sizeof(a));
-    a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : DH; a.hprev = t > 0 ? seq + at - slab : nullptr;
+    a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : DH; a.hprev = t > 0 ? seq + at - slab : h0;
     a.z = tr + R.oZ[l] + at; a.r = tr + R.oR[l] + at; a.hc = tr + R.oHC[l] + at;
     a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
     a.blend = prm->weights_gru + (size_t)l * T + t; a.dblend = g->weights_gru + (size_t)l * T + t;
@@ -437,6 +448,11 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
     RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
     RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
+  }
+  if (b.dH0) {   // what step 0 would carry into a step before it: dh + slot 0 of the gate AGCN's dA + its transposed mix
+    hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, DH, DAg, P.Ks > 0 ? MixOut : nullptr,
+                       b.dH0 + (size_t)l * B * N * H, B, N, Np, S);
+    CHECK_LAUNCH();
   }
   return MATGCN_OK;
 }
@@ -527,7 +543,8 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
   }
   float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
   float* Z2HA = tr + R.oZ2HA[par];
-  RETURN_IF(zero_async(Hprev, slab, ws));
+  if (h0) HIP_OK(hipMemcpyAsync(Hprev, h0, (size_t)slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
+  else RETURN_IF(zero_async(Hprev, slab, ws));
   if (T > 1)
     HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
   const size_t seqN = (size_t)T * slab;
@@ -546,6 +563,10 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
     // the zero state at t = 0 contributes nothing
     MixedRows none = {nullptr, 0, 0, 0, 0, 0, 0};
     RETURN_IF(node_weight_grad(bw, Hprev, none, H, DPG, 128, I, C, 0, rowsTB, dWpG, 1));
+    if (h0) {   // ... unless the forward started from a state: its mix at t = 0 stayed in the workspace block G_l
+      MixedRows m0 = {c.ws + P.oG[l], (long)B * P.Ks * H, H, 0, (long)P.Ks * H, 1, B};
+      RETURN_IF(node_weight_grad(bw, Hprev, m0, H, DPG, 128, I, C, 0, B, dWpG, 2));
+    }
     for (int t0 = 0; t0 < T;) {
       const int nt = chunk_steps(P, t0);
       const int ntm = T - 1 - t0 < nt ? T - 1 - t0 : nt;   // the block's last slot of the sequence feeds nobody here
@@ -619,7 +640,11 @@ int bwd_fuse_heads(Pass& pass) {
     RETURN_IF(zero_async(dgain, 64, s));
     FuseBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = b.X; a.dx0 = tr + R.oDX0; a.tsg = prm->weight_tsg; a.dgain = dgain;
+    a.X = b.src ? b.src->series : b.X; a.dx0 = tr + R.oDX0; a.tsg = prm->weight_tsg; a.dgain = dgain;
+    if (b.src) {
+      a.labelStart = b.src->label_start;
+      for (int s2 = 0; s2 < D->x_steps; ++s2) a.rel[s2] = b.src->rel_steps[s2];
+    }
     for (int h = 0; h < D->n_heads; ++h) {
       if (!g->weight_ts[h]) return MATGCN_ERR_NULL;
       a.ts[h] = prm->weight_ts[h]; a.dts[h] = g->weight_ts[h]; a.headBegin[h] = D->head_begin[h];
@@ -758,11 +783,13 @@ int backward_impl(Bwd& b, const float* dOut) {
   RETURN_IF(wavefront_ready());
   q.fusedLds = 128 * CF_LD * (int)sizeof(float);
   {
-    static bool optedIn = false;   // dynamic LDS above 64 KB must be opted into once
-    if (!optedIn) {
+    static bool optedIn[MAX_DEVICES] = {false};   // dynamic LDS above 64 KB must be opted into once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    if (!optedIn[dev]) {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, q.fusedLds));
-      optedIn = true;
+      optedIn[dev] = true;
     }
   }
   q.twoStreams = g_wavefront_mode != 0 && P.L > 1 && !P.gcnOff;
@@ -778,6 +805,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     LayerBufs L;
     L.l = l; L.C = P.Cl[l]; L.I = L.C + H; L.par = P.L > 1 ? (l & 1) : 0;
     L.seq = b.c.ws + P.oSeq[l];
+    L.h0 = b.hasH0 ? tr + R.oH0 + (size_t)l * P.B * P.Np * H : nullptr;
     L.dSeqCur = tr + R.oDSeq[cur];
     L.dXall = (l == 0) ? tr + R.oDX0 : tr + R.oDSeq[cur ^ 1];
     L.DPU = tr + R.oDPU[L.par]; L.DPG = tr + R.oDPG[L.par]; L.DPU2 = tr + R.oDPU2[L.par]; L.DPG2 = tr + R.oDPG2[L.par];
@@ -821,9 +849,10 @@ int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes) {
 }
 
 int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                         const float* drop_mask, float* out, void* workspace, size_t workspace_bytes, void* train,
-                         size_t train_bytes, void* stream) {
-  if (!prepared || !X || !out || !train) return MATGCN_ERR_NULL;
+                         const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
+                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
+  if (!prepared || (!X && !src) || !out || !train) return MATGCN_ERR_NULL;
+  if (src) RETURN_IF(check_series(dims, src->series, src->series_steps, src->label_start, src->rel_steps));
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
@@ -842,8 +871,9 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
     CHECK_LAUNCH();
   }
   float* x0p = c.ws + P.oX0p;
-  RETURN_IF(fuse_padded(c, X, x0p));
-  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  if (src) RETURN_IF(fuse_padded(c, src->series, x0p, src->label_start, src->rel_steps));
+  else RETURN_IF(fuse_padded(c, X, x0p));
+  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   const float* seqTop = c.ws + P.oSeq[P.L - 1];
   if (drop_mask) {   // mask (B, headT, N, H) on the steps the head convolves (fnn_off: the last one)
     const size_t ofs = (size_t)(P.T - P.headT) * P.B * P.Np * H;
@@ -857,15 +887,18 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
 }
 
 int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                    const float* drop_mask, const float* d_out, const matgcn_grads* grads, void* workspace,
-                    size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
-  if (!prepared || !X || !d_out || !grads || !train) return MATGCN_ERR_NULL;
+                    const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
+                    const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
+                    size_t train_bytes, void* stream) {
+  if (!prepared || (!X && !src) || !d_out || !grads || !train) return MATGCN_ERR_NULL;
+  if (src) RETURN_IF(check_series(dims, src->series, src->series_steps, src->label_start, src->rel_steps));
   Bwd b;
   RETURN_IF(make_ctx(&b.c, dims, params, prepared, workspace, workspace_bytes, stream));
   RETURN_IF(check_layer_params(dims, params));
   RETURN_IF(make_train_plan(b.c.P, &b.c.R));
   if (train_bytes < (size_t)b.c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   b.X = X; b.dropMask = drop_mask; b.g = grads; b.tr = (float*)train;
+  b.hasH0 = h0 != nullptr; b.dH0 = d_h0; b.src = src;
   return backward_impl(b, d_out);
 }
 

@@ -559,6 +559,22 @@ __global__ __launch_bounds__(256) void k_chain_cell_gate(ChainArgs a) {
   a.dpg[row * 128 + 64 + o] = a.dr[idx] * r * (1.f - r);
 }
 
+// gradient of a layer's initial state, unpadded (B, N, 64): dh + slot 0 of the gate AGCN's dA of step 0 + its transposed
+// mix - exactly what the fused chain kernel adds up as the carry into an earlier step (dA / mix null: dense GRU layer)
+__global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, const float* __restrict__ dA,
+                                                 const float* __restrict__ mix, float* __restrict__ out, int B, int N,
+                                                 int Np, int S) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)B * N * 64) return;
+  const int o = idx & 63;
+  const size_t row = idx >> 6, b = row / N, n = row - b * N;
+  const size_t p = (b * Np + n) * 64 + o;
+  float v = dh[p];
+  if (dA) v += dA[((b * S) * Np + n) * 64 + o];
+  if (mix) v += mix[p];
+  out[idx] = v;
+}
+
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
@@ -703,7 +719,9 @@ __global__ __launch_bounds__(256) void k_dout_rows(const float* __restrict__ dou
 // dx0 time-major [T][B][Np][C0]; one thread per (head, t, n, c): reduces over the batch
 //   dweight_ts[h][t][n][c] = g_h * sum_b dx0 * X ;  dgain[h] += sum dx0 * X * weight_ts[h]
 struct FuseBwdArgs {
-  const float* X;
+  const float* X;        // windows (B, xSteps, N, F), or the raw series (steps, N, F) when labelStart != null
+  const int* labelStart; // device (B) label starts, or null
+  int rel[256];          // series mode: row offsets relative to the label start (MATGCN_MAX_XSTEPS)
   const float* dx0;
   const float* tsg;
   const float* ts[8];
@@ -724,7 +742,9 @@ __global__ __launch_bounds__(256) void k_fuse_heads_bwd(FuseBwdArgs a) {
     const int t = idx / ((size_t)a.od * a.N);
     float s = 0.f;
     for (int b = 0; b < a.B; ++b) {
-      const float xv = a.X[(((size_t)b * a.xSteps + a.headBegin[h] + t) * a.N + n) * a.F + a.startDim + c];
+      const size_t xrow = a.labelStart ? (size_t)(a.labelStart[b] + a.rel[a.headBegin[h] + t])
+                                       : (size_t)b * a.xSteps + a.headBegin[h] + t;
+      const float xv = a.X[(xrow * a.N + n) * a.F + a.startDim + c];
       s = fmaf(a.dx0[(((size_t)t * a.B + b) * a.Np + n) * a.C0 + c], xv, s);
     }
     a.dts[h][idx] = stack_gain(a.tsg, a.nTs, h) * s;

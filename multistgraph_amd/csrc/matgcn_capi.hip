@@ -158,6 +158,7 @@ struct TrainPlan {
   long oZ[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS], oHC[MATGCN_MAX_LAYERS];
   long oZ2[MATGCN_MAX_LAYERS], oR2[MATGCN_MAX_LAYERS], oHC2[MATGCN_MAX_LAYERS];
   long oSeqDrop;                           // the top sequence after dropout (what the head saw), [T][B][Np][64]
+  long oH0;                                // [L][B][Np][64] the initial state as the forward packed it (zeros without h0)
   long savedFloats;                        // [0, savedFloats) is zeroed by forward_train
   // graph-mixed rows of every step as the forward wrote them, [T][N][B][Ks][64] (x part: per chunk [N][nt*B][Ks][64],
   // which also holds the recurrent mix of the layer below; oGH exists for the top layer only);
@@ -189,6 +190,7 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
     R->oZ2[l] = take(seq); R->oR2[l] = take(seq); R->oHC2[l] = take(seq);
   }
   R->oSeqDrop = take(seq);
+  R->oH0 = take(slab * P.L);
   R->savedFloats = o;
   const long gAll = (long)P.T * P.N * P.B * P.Ks * H;
   for (int l = 0; l < P.L; ++l) {
@@ -291,7 +293,17 @@ struct Wavefront {
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
   hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
 };
-Wavefront g_wf;
+// one set per device ordinal: a HIP stream / event belongs to the device that was current when it was created, so a
+// process that drives several GPUs (or the rehearsal runs that put two ranks on one box) must not share them.
+// (One host thread per device at a time, like the rest of the library: the reference is single-threaded too.)
+constexpr int MAX_DEVICES = 64;
+Wavefront g_wfs[MAX_DEVICES];
+inline Wavefront& wf_current() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  return g_wfs[dev];
+}
+#define g_wf (wf_current())
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
 
 int wavefront_ready() {
@@ -378,7 +390,10 @@ struct Ctx {
 constexpr int GATE_LDS = 3 * 4096 * (int)sizeof(float);
 constexpr int UPDATE_LDS = 4 * 4096 * (int)sizeof(float);
 int node_kernels_ready(int ldsBytes) {
-  static int ready = 0;
+  static int readyOn[MAX_DEVICES] = {0};   // function attributes are per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  int& ready = readyOn[dev];
   if (ready >= ldsBytes) return MATGCN_OK;
   const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false>), at, GATE_LDS));
@@ -576,6 +591,12 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
     hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, cs,
                        h0User ? h0User + (size_t)l * P.B * P.N * H : nullptr, c.ws + P.oHx[l], P.B, P.N, P.Np, H);
     CHECK_LAUNCH();
+    if (c.train && h0User) {   // the backward needs h_{-1} of every layer (gate algebra, weight gradients of step 0)
+      hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, cs,
+                         h0User + (size_t)l * P.B * P.N * H, c.train + c.R.oH0 + (size_t)l * P.B * P.Np * H, P.B, P.N,
+                         P.Np, H);
+      CHECK_LAUNCH();
+    }
     const float* below = (l == 0) ? nullptr : c.ws + P.oSeq[l - 1];
     float* seq = c.ws + P.oSeq[l];
     const long stepRows = (long)P.B * P.Np * H;     // one step of a time-major sequence
@@ -739,32 +760,33 @@ extern "C" {
 
 int matgcn_abi_version(void) { return MATGCN_ABI_VERSION; }
 
-int matgcn_masked_mae(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
-                      int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
-                      float* partials, float* result, void* stream) {
+int matgcn_masked_mae(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps, int nodes,
+                      int out_dim, int y_steps, int y_feat, int y_start, float mean, float std, float null_val,
+                      float min_s, float* partials, float* result, void* stream) {
   if (!pred || !y || !partials || !result) return MATGCN_ERR_NULL;
   if (batch < 1 || out_steps < 1 || out_steps > 64 || nodes < 1 || out_dim < 1 || y_steps < out_steps ||
       y_start < 0 || y_start + out_dim > y_feat)
     return MATGCN_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_mae_partial, dim3((unsigned)(batch * out_steps)), dim3(256), 0, s, pred, y, out_steps, nodes,
-                     out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s, partials);
+  hipLaunchKernelGGL(k_mae_partial, dim3((unsigned)(batch * out_steps)), dim3(256), 0, s, pred, y, label_start, out_steps,
+                     nodes, out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s, partials);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(k_mae_final, dim3(1), dim3(64), 0, s, partials, batch, out_steps, result);
   return launch_ok();
 }
 
-int matgcn_masked_mae_grad(const float* pred, const float* y, int batch, int out_steps, int nodes, int out_dim,
-                           int y_steps, int y_feat, int y_start, float mean, float std, float null_val, float min_s,
-                           const float* partials, const float* upstream, float* d_pred, void* stream) {
+int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps,
+                           int nodes, int out_dim, int y_steps, int y_feat, int y_start, float mean, float std,
+                           float null_val, float min_s, const float* partials, const float* upstream, float* d_pred,
+                           void* stream) {
   if (!pred || !y || !partials || !upstream || !d_pred) return MATGCN_ERR_NULL;
   if (batch < 1 || out_steps < 1 || out_steps > 64 || nodes < 1 || out_dim < 1 || y_steps < out_steps ||
       y_start < 0 || y_start + out_dim > y_feat)
     return MATGCN_ERR_BAD_ARG;
   const size_t total = (size_t)batch * out_steps * nodes * out_dim;
-  hipLaunchKernelGGL(k_mae_grad, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, pred, y, out_steps, nodes,
-                     out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s, partials + 2 * (size_t)batch * out_steps,
-                     upstream, total, d_pred);
+  hipLaunchKernelGGL(k_mae_grad, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, pred, y, label_start,
+                     out_steps, nodes, out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s,
+                     partials + 2 * (size_t)batch * out_steps, upstream, total, d_pred);
   return launch_ok();
 }
 
@@ -953,7 +975,7 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
 }
 
 int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                   float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                   const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared || !X || !out) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
@@ -963,29 +985,36 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, X, x0p));
-  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+}
+
+// the host-visible part of the series range contract: no window row may start before the series
+static int check_series(const matgcn_dims* dims, const float* series, int64_t series_steps, const int32_t* label_start,
+                 const int32_t* rel_steps) {
+  if (!series || !label_start || !rel_steps) return MATGCN_ERR_NULL;
+  if (dims->x_steps > MATGCN_MAX_XSTEPS) return MATGCN_ERR_UNSUPPORTED;
+  int lo = 0;
+  for (int s2 = 0; s2 < dims->x_steps; ++s2) lo = rel_steps[s2] < lo ? rel_steps[s2] : lo;
+  if (series_steps < 1 || -(int64_t)lo >= series_steps) return MATGCN_ERR_BAD_ARG;
+  return MATGCN_OK;
 }
 
 int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                           const float* series, int64_t series_steps, const int32_t* label_start,
-                          const int32_t* rel_steps, float* out, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          const int32_t* rel_steps, const float* h0, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   if (!prepared || !series || !label_start || !rel_steps || !out) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));
-  if (dims->x_steps > MATGCN_MAX_XSTEPS) return MATGCN_ERR_UNSUPPORTED;
-  // the host-visible part of the range contract: no window row may start before the series
-  int lo = 0;
-  for (int s2 = 0; s2 < dims->x_steps; ++s2) lo = rel_steps[s2] < lo ? rel_steps[s2] : lo;
-  if (series_steps < 1 || -(int64_t)lo >= series_steps) return MATGCN_ERR_BAD_ARG;
+  RETURN_IF(check_series(dims, series, series_steps, label_start, rel_steps));
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
   RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps));
-  RETURN_IF(encoder_padded(c, x0p, nullptr, nullptr));
+  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
 }
 

@@ -600,14 +600,16 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 // 9. loss / metric epilogue (MultiATGCN.py:422-427, loss.py:17-29, traffic_state_evaluator.py:87-104)
 // =================================================================================================
 // stage 1: one workgroup per (b, horizon): sum |p-l|*mask and sum mask over the N*od values of that slab
+// (labelStart != null: y is the raw series (steps, N, yFeat), label row (b, o) = y[labelStart[b] + o])
 __global__ __launch_bounds__(256) void k_mae_partial(const float* __restrict__ pred, const float* __restrict__ y,
-                                                     int outSteps, int N, int od, int ySteps, int yFeat, int yStart,
-                                                     float mean, float std, float nullVal, float minS,
-                                                     float* __restrict__ partials) {
+                                                     const int* __restrict__ labelStart, int outSteps, int N, int od,
+                                                     int ySteps, int yFeat, int yStart, float mean, float std,
+                                                     float nullVal, float minS, float* __restrict__ partials) {
   __shared__ float sAbs[256], sCnt[256];
   const int b = blockIdx.x / outSteps, o = blockIdx.x - b * outSteps;
   const float* pp = pred + ((size_t)b * outSteps + o) * N * od;
-  const float* yp = y + ((size_t)b * ySteps + o) * N * yFeat + yStart;
+  const size_t yrow = labelStart ? (size_t)labelStart[b] + o : (size_t)b * ySteps + o;
+  const float* yp = y + yrow * N * yFeat + yStart;
   const bool nanMask = nullVal != nullVal;
   float sa = 0.f, sc = 0.f;
   for (int idx = threadIdx.x; idx < N * od; idx += 256) {
@@ -651,8 +653,9 @@ __global__ __launch_bounds__(64) void k_mae_final(const float* __restrict__ part
 // gradient of result[0] w.r.t. pred: upstream * std * sign(p - l) * mask / sum(mask)   (torch: d|x| = sign(x), 0 at 0;
 // terms the forward replaced by 0 - NaN differences - get no gradient)
 __global__ __launch_bounds__(256) void k_mae_grad(const float* __restrict__ pred, const float* __restrict__ y,
-                                                  int outSteps, int N, int od, int ySteps, int yFeat, int yStart,
-                                                  float mean, float std, float nullVal, float minS,
+                                                  const int* __restrict__ labelStart, int outSteps, int N, int od,
+                                                  int ySteps, int yFeat, int yStart, float mean, float std,
+                                                  float nullVal, float minS,
                                                   const float* __restrict__ count, const float* __restrict__ upstream,
                                                   size_t total, float* __restrict__ dpred) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -661,7 +664,8 @@ __global__ __launch_bounds__(256) void k_mae_grad(const float* __restrict__ pred
   const int n = (idx / od) % N;
   const int o = (idx / ((size_t)od * N)) % outSteps;
   const size_t b = idx / ((size_t)od * N * outSteps);
-  float l = y[((b * ySteps + o) * N + n) * yFeat + yStart + c] * std + mean;
+  const size_t yrow = labelStart ? (size_t)labelStart[b] + o : b * ySteps + o;
+  float l = y[(yrow * N + n) * yFeat + yStart + c] * std + mean;
   const float p = pred[idx] * std + mean;
   if (fabsf(l) < minS) l = 0.f;
   const bool nanMask = nullVal != nullVal;

@@ -56,9 +56,10 @@ def inverse_euclid(static: Optional[np.ndarray], n: int) -> np.ndarray:
     if static is None:
         return np.eye(n, dtype=np.float32)
     s = np.asarray(static, dtype=np.float64)
-    sq = (s * s).sum(1)
-    d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * s @ s.T, 0.0)
-    dist = np.sqrt(d2)
+    dist = np.empty((s.shape[0], s.shape[0]), dtype=np.float64)
+    for r0 in range(0, s.shape[0], 64):     # direct differences like scipy's cdist (exact zeros on the diagonal and for
+        diff = s[r0:r0 + 64, None, :] - s[None, :, :]                      # duplicate rows), a block of rows at a time
+        dist[r0:r0 + 64] = np.sqrt((diff * diff).sum(-1))
     dist[dist == 0] = 1.0
     return (1.0 / dist).astype(np.float32)
 

@@ -14,6 +14,7 @@ this class.
 from __future__ import annotations
 
 import math
+from collections import OrderedDict
 from logging import getLogger
 from typing import Dict, Optional
 
@@ -107,9 +108,10 @@ class _TrainStep(torch.autograd.Function):
     never differentiates w.r.t. the batch)."""
 
     @staticmethod
-    def forward(ctx, path, x, drop_mask, names, *params):
-        out = path.forward_train(x, drop_mask)
-        ctx.path, ctx.x, ctx.mask, ctx.names = path, x, drop_mask, names
+    def forward(ctx, path, x, drop_mask, h0, names, *params):
+        h0 = None if h0 is None else h0.detach()
+        out = path.forward_train(x, drop_mask, h0)
+        ctx.path, ctx.x, ctx.mask, ctx.names, ctx.h0 = path, x, drop_mask, names, h0
         ctx.params = params
         ctx.generation = path.train_generation
         return out
@@ -121,9 +123,11 @@ class _TrainStep(torch.autograd.Function):
             raise RuntimeError("MultiATGCN backward: another forward ran on this model between this forward and its "
                                "backward; the saved activations live in the shared workspace (one graph at a time)")
         state = {k: p for k, p in zip(ctx.names, ctx.params)}
-        grads = path.backward(ctx.x, d_out.contiguous(), state, ctx.mask)
-        return (None, None, None, None) + tuple(grads.get(k) if p.requires_grad else None
-                                                for k, p in zip(ctx.names, ctx.params))
+        grads = path.backward(ctx.x, d_out.contiguous(), state, ctx.mask, ctx.h0)
+        # the initial state (static features, :406-409) gets its gradient back: torch autograd carries it on through
+        # expand() and static_initial_gru
+        return (None, None, None, grads.get(path.D_H0), None) + tuple(grads.get(k) if p.requires_grad else None
+                                                                      for k, p in zip(ctx.names, ctx.params))
 
 
 class MultiATGCN(AbstractTrafficStateModel):
@@ -154,9 +158,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         assert self.num_layers >= 1, "At least one recurrent layer in the encoder"
         if self.add_day_in_week and not self.add_time_in_day:
             raise ValueError("add_day_in_week without add_time_in_day is undefined in the reference (:313-318)")
-        if data_feature.get("static", None) is not None:
-            raise NotImplementedError("add_static (PCA initial state, :286-296,:406-409) is not built yet: "
-                                      "pass static=None (DESIGN.md, out of scope this round)")
+        static = data_feature.get("static", None)
         if self.input_window != 24:
             raise ValueError("the reference fuses 24-step heads (:373-393): input_window must be 24")
         embed_dim_cfg = self.embed_dim_node
@@ -165,7 +167,7 @@ class MultiATGCN(AbstractTrafficStateModel):
 
         # ---- one-off host graph prep (:238-283) -> first-order static supports (fp32, host)
         mats = graph_prep.build_static_supports(data_feature.get("adj_mx"), data_feature.get("coordinate"),
-                                                None, self.adjtype)
+                                                None if static is None else np.asarray(static), self.adjtype)
         use_static = self.adpadj == "none" or self.adjtype == "multi"  # (:87-93)
         self._static_host = torch.from_numpy(np.stack(mats, 0)) if use_static else None
         self._static_dev: Optional[torch.Tensor] = None
@@ -177,7 +179,21 @@ class MultiATGCN(AbstractTrafficStateModel):
         # torch.manual_seed gives bit-identical initial weights: the randn of (:296) - drawn at the CONFIG width even
         # under node_specific_off (the reference shrinks its own embed_dim_node only at :351) -, the nn.Linear /
         # Conv2d constructors, then _init_parameters over parameters() in registration order.
-        self.node_emb = nn.Parameter(torch.randn(n, embed_dim_cfg))
+        # With static features (add_static, :286-294): static_initial_node is registered first (it stays in the
+        # state_dict although forward never uses it), torch.pca_lowrank draws from the generator, and node_emb starts
+        # from static_initial_node(static @ v) - only to be re-initialised by _init_parameters like everything else.
+        self._static_q = min(n, embed_dim_cfg)
+        if static is not None:
+            st = torch.as_tensor(np.asarray(static), dtype=torch.float32)
+            self.register_buffer("static", st, persistent=False)   # follows model.to(device); not in the state_dict
+            self.static_initial_node = nn.Sequential(OrderedDict(
+                [("embd", nn.Linear(self._static_q, embed_dim_cfg, bias=True)), ("relu1", nn.ReLU())]))
+            _, _, v = torch.pca_lowrank(st, q=self._static_q)
+            with torch.no_grad():
+                self.node_emb = nn.Parameter(self.static_initial_node(torch.matmul(st, v)))
+        else:
+            self.static = None
+            self.node_emb = nn.Parameter(torch.randn(n, embed_dim_cfg))
         self.node_vec1 = nn.Parameter(torch.empty(n, rank))
         self.node_vec2 = nn.Parameter(torch.empty(rank, n))
         self.spec: PathSpec = spec_from_config(config, data_feature, n, rank,
@@ -189,6 +205,9 @@ class MultiATGCN(AbstractTrafficStateModel):
         self.weight_ts = nn.ParameterList(
             [nn.Parameter(torch.empty(1, 24, n, self.output_dim)) for _ in range(self.len_ts)])
         self.weight_tsg = nn.Parameter(torch.empty(self.len_ts))
+        if static is not None:   # initial state of the encoder from the static features (:335-338)
+            self.static_initial_gru = nn.Sequential(OrderedDict(
+                [("embd", nn.Linear(self._static_q, self.hidden_dim, bias=True)), ("relu1", nn.ReLU())]))
         self.encoder = _EncoderParams(self.num_layers, self.input_window, self.feature_final, self.hidden_dim,
                                       self.spec.k_total, self.embed_dim_node, self.gcn_off)
         self.end_conv = nn.Conv2d(self.input_window, self.output_window * self.output_dim,
@@ -217,6 +236,16 @@ class MultiATGCN(AbstractTrafficStateModel):
     def _state(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach() for k, v in self.named_parameters()}
 
+    def _initial_state(self, batch: int) -> Optional[torch.Tensor]:
+        """(L, B, N, H) initial encoder state from the static features, or None (zeros): a PCA of the static table and
+        one nn.Linear + ReLU, expanded over layers and samples (:405-409).  Host-side torch - tiny, and the PCA is
+        torch.pca_lowrank exactly as in the reference (randomised: it draws from torch's generator on every forward)."""
+        if self.static is None:
+            return None
+        _, _, v = torch.pca_lowrank(self.static, q=self._static_q)
+        emb = self.static_initial_gru(torch.matmul(self.static, v))
+        return emb.expand(self.num_layers, batch, -1, -1)
+
     def _params_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
@@ -242,44 +271,103 @@ class MultiATGCN(AbstractTrafficStateModel):
         return hp
 
     # ---- the plugin surface the executor calls ---------------------------------------------------
-    def forward(self, batch):
-        x = batch["X"]
-        assert x.shape[2] == self.num_nodes  # (:195)
-        if x.dtype != torch.float32:
-            x = x.float()
-        x = x.contiguous()
+    def _run(self, source, batch: int, device):
+        """One forward on the HIP path.  source: the windows tensor X, or a (series, label_start, rel_steps) triple
+        (device-resident raw series).  Inference under no_grad / eval; with gradients
+        enabled the training form (activations kept, HIP backward behind torch autograd)."""
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        h0 = self._initial_state(batch)
+        h0 = None if h0 is None else h0.contiguous()
+        hp = self._path_for_batch(batch, device)
         if not needs_grad:
             if self.training:
                 raise NotImplementedError("training-mode forward (dropout, :416) without autograd is not built: "
                                           "call model.eval() for inference")
-            return self._path_for(x).forward(x)
+            if isinstance(source, torch.Tensor):
+                return hp.forward(source, h0)
+            return hp.forward_series(source[0], source[1], source[2], h0)
         # training step: HIP forward that keeps its activations + HIP backward behind torch autograd
-        hp = self._path_for(x)
         mask = None
         if self.training:   # F.dropout(output, p=0.1) in front of end_conv (:416), drawn from torch's generator
-            mask = nn.functional.dropout(torch.ones(x.shape[0], 1 if self.fnn_off else self.input_window,
-                                                    self.num_nodes, self.hidden_dim, device=x.device),
+            mask = nn.functional.dropout(torch.ones(batch, 1 if self.fnn_off else self.input_window,
+                                                    self.num_nodes, self.hidden_dim, device=device),
                                          p=0.1, training=True)   # fnn_off keeps the last step only (:412)
-        named = list(self.named_parameters())
-        return _TrainStep.apply(hp, x, mask, tuple(k for k, _ in named), *[p for _, p in named])
+        # static_initial_* are host-side torch layers: their gradients flow through h0, not through the HIP backward
+        named = [(k, p) for k, p in self.named_parameters() if not k.startswith("static_initial")]
+        return _TrainStep.apply(hp, source, mask, h0, tuple(k for k, _ in named), *[p for _, p in named])
+
+    def forward(self, batch):
+        x = batch["X"]
+        assert x.shape[2] == self.num_nodes  # (:195)
+        if not x.is_cuda:
+            raise RuntimeError("MultiATGCN.forward runs on the HIP hot path only: batch['X'] is on %s. "
+                               "Move the model and the batch to the GPU (config['device'])." % x.device)
+        if x.dtype != torch.float32:
+            x = x.float()
+        return self._run(x.contiguous(), int(x.shape[0]), x.device)
 
     def predict(self, batch):
         return self.forward(batch)
 
-    def predict_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
-        """predict() without materialised windows: ``series`` (T, N, F) float32 resident on the GPU, ``label_start``
-        (B) int32 first-target indices; the window rows are gathered on the device (windows.window_offsets gives
-        ``rel_steps``; the default is the reference's 2 x 24 h closeness + 1-week + 4-week heads)."""
+    # ---- the same surface fed from the device-resident raw series (no windows, no labels materialised) ----------
+    def _series_source(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps):
         from . import windows
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("forward only: call under torch.no_grad()")
         if rel_steps is None:
             rel_steps = windows.window_offsets(self.input_window)
         if not series.is_cuda:
-            raise RuntimeError("predict_series needs the series on the GPU (HIP path only)")
-        hp = self._path_for_batch(int(label_start.shape[0]), series.device)
-        return hp.forward_series(series, label_start.to(torch.int32), rel_steps)
+            raise RuntimeError("the series must live on the GPU (HIP path only)")
+        return (series, label_start.to(torch.int32), rel_steps)
+
+    def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+        """forward() without materialised windows: ``series`` (T, N, F) float32 resident on the GPU, ``label_start``
+        (B) first-target indices; the window rows are gathered on the device (windows.window_offsets gives
+        ``rel_steps``; the default is the reference's 2 x 24 h closeness + 1-week + 4-week heads).  Replaces
+        MTHDataset._generate_input_data + the per-batch host copy (mth_dataset.py:110-160, data/utils.py:68-72,
+        batch.py:43-57); trains like forward() when gradients are enabled."""
+        src = self._series_source(series, label_start, rel_steps)
+        return self._run(src, int(label_start.shape[0]), series.device)
+
+    def predict_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+        return self.forward_series(series, label_start, rel_steps)
+
+    def calculate_loss_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+        """calculate_loss (:422-427) of the batch given by ``label_start``: the prediction from the series-fed forward,
+        the targets series[label_start[b] + o] gathered by the loss kernel on the device.  With gradients enabled this is
+        the executor's training step (traffic_state_executor.py:411-422) without any host-side window or label."""
+        pred = self.forward_series(series, label_start, rel_steps)
+        ls = label_start.to(torch.int32)
+        affine = self._affine_scaler()
+        if affine is not None and series.dtype == torch.float32:
+            if pred.requires_grad:
+                return masked_mae_loss(pred, series, self.start_dim, affine[0], affine[1], null_val=0.0, label_start=ls)
+            return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1], null_val=0.0, label_start=ls)[0]
+        rows = ls.long()[:, None] + torch.arange(self.output_window, device=series.device)[None, :]
+        y_true = self._scaler.inverse_transform(series[rows][..., self.start_dim:self.end_dim].clone())
+        return masked_mae(self._scaler.inverse_transform(pred), y_true, 0)
+
+    def horizon_mae_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+        """(out,) MAE@1..MAE@out of the batch given by ``label_start`` (evaluator "single" mode), all on the device."""
+        affine = self._affine_scaler()
+        if affine is None:
+            raise NotImplementedError("horizon_mae_series needs an affine scaler (StandardScaler / NoneScaler)")
+        pred = self.forward_series(series, label_start, rel_steps)
+        return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1],
+                                 label_start=label_start.to(torch.int32))[1:]
+
+    def gradient_bucket(self) -> Optional[torch.Tensor]:
+        """The flat fp32 buffer that holds the gradient of every HIP-path parameter after ``loss.backward()`` (their
+        ``.grad`` are views of it), for ONE all-reduce in data-parallel training (sharding.bucket_allreduce_mean_);
+        None when some gradient lives elsewhere (accumulated gradients, a second batch size) - then exchange the
+        ``.grad`` tensors themselves.  The host-side static_initial_* layers are not part of it."""
+        for hp in self._paths.values():
+            b = hp.grad_bucket
+            if b is None:
+                continue
+            lo, hi = b.data_ptr(), b.data_ptr() + b.numel() * 4
+            mine = [p for k, p in self.named_parameters() if p.requires_grad and not k.startswith("static_initial")]
+            if mine and all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in mine):
+                return b
+        return None
 
     def _affine_scaler(self):
         """(mean, std) when the scaler de-scales as x*std + mean with scalar parameters (LibCity's StandardScaler /

@@ -152,37 +152,54 @@ def debug_gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, desc, alpha=1.
                                      C.c_float(alpha), C.c_float(beta), stream), "matgcn_debug_gemm")
 
 
-def _mae_call(pred, y, y_start, mean, std, null_val, min_s):
+def _label_geometry(pred, y, label_start):
+    """(y, label_start, y_steps, y_feat) checked: y is (B, y_steps, N, F) windows, or - with label_start (B) int32 -
+    the raw series (T, N, F) whose rows label_start[b] .. +out are sample b's targets"""
+    b, out, n, od = pred.shape
+    y = _check_tensor(y, "y")
+    if label_start is None:
+        if y.dim() != 4 or y.shape[0] != b or y.shape[2] != n:
+            raise _lib.MatgcnError("y has shape %s, incompatible with pred %s" % (tuple(y.shape), tuple(pred.shape)))
+        return y, None, int(y.shape[1]), int(y.shape[3])
+    if y.dim() != 3 or y.shape[1] != n:
+        raise _lib.MatgcnError("series has shape %s, expected (T, %d, F)" % (tuple(y.shape), n))
+    if not label_start.is_cuda or label_start.dtype != torch.int32 or tuple(label_start.shape) != (b,):
+        raise _lib.MatgcnError("label_start must be a CUDA int32 tensor of shape (%d,)" % b)
+    return y, label_start.contiguous(), int(y.shape[0]), int(y.shape[2])
+
+
+def _mae_call(pred, y, y_start, mean, std, null_val, min_s, label_start=None):
     lib = _lib.load()
     pred = _check_tensor(pred, "pred")
-    y = _check_tensor(y, "y")
     b, out, n, od = pred.shape
-    if y.dim() != 4 or y.shape[0] != b or y.shape[2] != n:
-        raise _lib.MatgcnError("y has shape %s, incompatible with pred %s" % (tuple(y.shape), tuple(pred.shape)))
+    y, label_start, y_steps, y_feat = _label_geometry(pred, y, label_start)
     partials = torch.empty(2 * b * out + 1, dtype=torch.float32, device=pred.device)
     result = torch.empty(1 + out, dtype=torch.float32, device=pred.device)
     stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
-    _lib.check(lib.matgcn_masked_mae(C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), b, out, n, od,
-                                     int(y.shape[1]), int(y.shape[3]), int(y_start), float(mean), float(std),
+    _lib.check(lib.matgcn_masked_mae(C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(_ptr(label_start)),
+                                     b, out, n, od, y_steps, y_feat, int(y_start), float(mean), float(std),
                                      float(null_val), float(min_s), C.c_void_p(partials.data_ptr()),
                                      C.c_void_p(result.data_ptr()), stream), "matgcn_masked_mae")
-    return pred, y, partials, result
+    return pred, y, partials, result, label_start
 
 
 def masked_mae_device(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
-                      null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
+                      null_val: float = float("nan"), min_s: float = 1e-4,
+                      label_start: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(1 + out,) tensor [masked-MAE over all horizons, MAE@1 .. MAE@out] computed on the device by
-    matgcn_masked_mae (de-scale + mask + reduce; reference loss.py:17-29, traffic_state_evaluator.py:87-104)."""
-    return _mae_call(pred, y, y_start, mean, std, null_val, min_s)[3]
+    matgcn_masked_mae (de-scale + mask + reduce; reference loss.py:17-29, traffic_state_evaluator.py:87-104).
+    With label_start, y is the raw series and the targets are gathered on the device."""
+    return _mae_call(pred, y, y_start, mean, std, null_val, min_s, label_start)[3]
 
 
 class _MaskedMAE(torch.autograd.Function):
     """calculate_loss on the device with its gradient (matgcn_masked_mae / matgcn_masked_mae_grad)."""
 
     @staticmethod
-    def forward(ctx, pred, y, y_start, mean, std, null_val, min_s):
-        pred_c, y_c, partials, result = _mae_call(pred.detach(), y, y_start, mean, std, null_val, min_s)
+    def forward(ctx, pred, y, y_start, mean, std, null_val, min_s, label_start):
+        pred_c, y_c, partials, result, ls = _mae_call(pred.detach(), y, y_start, mean, std, null_val, min_s, label_start)
         ctx.save_for_backward(pred_c, y_c, partials)
+        ctx.label_start = ls
         ctx.args = (int(y_start), float(mean), float(std), float(null_val), float(min_s))
         return result[0].clone()
 
@@ -191,20 +208,24 @@ class _MaskedMAE(torch.autograd.Function):
         pred, y, partials = ctx.saved_tensors
         y_start, mean, std, null_val, min_s = ctx.args
         b, out, n, od = pred.shape
+        ls = ctx.label_start
+        y_steps, y_feat = (int(y.shape[1]), int(y.shape[3])) if ls is None else (int(y.shape[0]), int(y.shape[2]))
         d_pred = torch.empty_like(pred)
         up = upstream.detach().to(torch.float32).reshape(1).contiguous()
         stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
         _lib.check(_lib.load().matgcn_masked_mae_grad(
-            C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), b, out, n, od, int(y.shape[1]), int(y.shape[3]),
+            C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(_ptr(ls)), b, out, n, od, y_steps, y_feat,
             y_start, mean, std, null_val, min_s, C.c_void_p(partials.data_ptr()), C.c_void_p(up.data_ptr()),
             C.c_void_p(d_pred.data_ptr()), stream), "matgcn_masked_mae_grad")
-        return d_pred, None, None, None, None, None, None
+        return d_pred, None, None, None, None, None, None, None
 
 
 def masked_mae_loss(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: float, std: float,
-                    null_val: float = float("nan"), min_s: float = 1e-4) -> torch.Tensor:
-    """The calculate_loss scalar with autograd support: the device reduction forward, matgcn_masked_mae_grad backward."""
-    return _MaskedMAE.apply(pred, y, y_start, mean, std, null_val, min_s)
+                    null_val: float = float("nan"), min_s: float = 1e-4,
+                    label_start: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The calculate_loss scalar with autograd support: the device reduction forward, matgcn_masked_mae_grad backward.
+    With label_start, y is the raw series and the targets are gathered on the device."""
+    return _MaskedMAE.apply(pred, y, y_start, mean, std, null_val, min_s, label_start)
 
 
 class HotPath:
@@ -227,6 +248,8 @@ class HotPath:
         self._prepared_ok = False
         self._train = None
         self.train_generation = 0
+        self.grad_bucket: Optional[torch.Tensor] = None   # flat buffer the gradients of backward() are views of
+        self._grad_key = None
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _stream(self):
@@ -299,15 +322,46 @@ class HotPath:
         if not self._prepared_ok:
             self.prepare()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _source(self, x):
+        """The batch of a training step: a windows tensor X (B, x_steps, N, F), or a (series, label_start, rel_steps)
+        triple - the raw series (T, N, F) resident on the device, B int32 label starts, the x_steps row offsets.
+        Returns (X pointer or None, matgcn_series or None, objects to keep alive)."""
+        s = self.spec
+        if isinstance(x, torch.Tensor):
+            x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+            return x.data_ptr(), None, (x,)
+        series, label_start, rel_steps = x
+        if series.dim() != 3 or tuple(series.shape[1:]) != (s.nodes, s.x_feat):
+            raise _lib.MatgcnError("series has shape %s, expected (T, %d, %d)" % (tuple(series.shape), s.nodes, s.x_feat))
+        series = _check_tensor(series, "series")
+        if not label_start.is_cuda or label_start.dtype != torch.int32 or tuple(label_start.shape) != (self.batch,):
+            raise _lib.MatgcnError("label_start must be a CUDA int32 tensor of shape (%d,)" % self.batch)
+        rel = [int(v) for v in rel_steps]
+        if len(rel) != s.x_steps:
+            raise _lib.MatgcnError("rel_steps has %d entries, x_steps is %d" % (len(rel), s.x_steps))
+        label_start = label_start.contiguous()
+        rel_c = (C.c_int32 * len(rel))(*rel)
+        src = _lib.Series(series.data_ptr(), int(series.shape[0]), label_start.data_ptr(), rel_c)
+        return None, src, (series, label_start, rel_c)
+
+    def _h0(self, h0):
+        """initial encoder state (L, B, N, H) or None = zeros (MultiATGCN.py:405-409)"""
+        if h0 is None:
+            return None
+        s = self.spec
+        return _check_tensor(h0, "h0", (s.layers, self.batch, s.nodes, s.hidden))
+
+    def forward(self, x: torch.Tensor, h0: Optional[torch.Tensor] = None) -> torch.Tensor:
         s = self.spec
         x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        h0 = self._h0(h0)
         self._need_prepared()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
         ws, wsb = self._ws()
         _lib.check(self.lib.matgcn_forward(C.byref(self.dims), C.byref(self.params),
                                            C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
-                                           C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward")
+                                           C.c_void_p(_ptr(h0)), C.c_void_p(out.data_ptr()), ws, wsb, self._stream()),
+                   "matgcn_forward")
         return out
 
     # ---- training step (SURVEY.md section 8, row f-1) ---------------------------------------------------
@@ -324,38 +378,70 @@ class HotPath:
         s = self.spec
         return _check_tensor(drop_mask, "drop_mask", (self.batch, 1 if s.fnn_off else s.in_steps, s.nodes, s.hidden))
 
-    def forward_train(self, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_train(self, x, drop_mask: Optional[torch.Tensor] = None,
+                      h0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """matgcn_forward that keeps the activations the backward needs (in the train buffer and the workspace).
-        drop_mask: the (B, T, N, H) multipliers of the dropout in front of end_conv (training mode) or None."""
+        x: the windows tensor X, or a (series, label_start, rel_steps) triple (see _source).
+        drop_mask: the (B, T, N, H) multipliers of the dropout in front of end_conv (training mode) or None;
+        h0: initial encoder state (L, B, N, H) or None."""
         s = self.spec
-        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        xp, src, _keep = self._source(x)
         drop_mask = self._mask(drop_mask)
+        h0 = self._h0(h0)
         self._need_prepared()
         tr = self._train_buffer()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
         ws, wsb = self._ws()
         _lib.check(self.lib.matgcn_forward_train(C.byref(self.dims), C.byref(self.params),
-                                                 C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
-                                                 C.c_void_p(_ptr(drop_mask)),
+                                                 C.c_void_p(self.prepared.data_ptr()), C.c_void_p(xp),
+                                                 C.byref(src) if src is not None else None,
+                                                 C.c_void_p(_ptr(h0)), C.c_void_p(_ptr(drop_mask)),
                                                  C.c_void_p(out.data_ptr()), ws, wsb, C.c_void_p(tr.data_ptr()),
                                                  C.c_size_t(tr.numel() * 4), self._stream()), "matgcn_forward_train")
         return out
 
-    def backward(self, x: torch.Tensor, d_out: torch.Tensor, state: Dict[str, torch.Tensor],
-                 drop_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    D_H0 = "__d_h0__"   # key of the initial-state gradient in backward()'s result
+
+    def _grad_views(self, state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Every gradient matgcn_backward returns is a view of ONE flat fp32 buffer (``grad_bucket``, 15.5 MB at
+        N = 403), so that the gradient exchange of data-parallel training is a single all-reduce of that buffer with no
+        concatenation or copy-back (torch autograd adopts the views as ``p.grad``).  The buffer is reused from step to
+        step - unless a parameter's ``.grad`` still lives in it (gradient accumulation, zero_grad(set_to_none=False)):
+        overwriting it would corrupt the sum autograd is about to form, so that call gets a buffer of its own."""
+        names = [k for k in state if not k.startswith("static_initial")]
+        key = tuple((k, tuple(state[k].shape)) for k in names)
+        offs, total = {}, 0
+        for k in names:
+            offs[k] = total
+            total += (state[k].numel() + 63) // 64 * 64        # every view starts on a 256-byte boundary
+        bucket = self.grad_bucket if self._grad_key == key else None
+        if bucket is not None:
+            lo, hi = bucket.data_ptr(), bucket.data_ptr() + bucket.numel() * 4
+            if any(getattr(state[k], "grad", None) is not None and lo <= state[k].grad.data_ptr() < hi for k in names):
+                bucket = torch.zeros(total, dtype=torch.float32, device=self.device)    # one-off, not kept
+        else:
+            bucket = self.grad_bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
+            self._grad_key = key
+        return {k: bucket[offs[k]:offs[k] + state[k].numel()].view(state[k].shape) for k in names}
+
+    def backward(self, x, d_out: torch.Tensor, state: Dict[str, torch.Tensor],
+                 drop_mask: Optional[torch.Tensor] = None, h0: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Gradients of every tensor of `state` (the dict bind() saw) that the loss depends on, keyed by the same
-        names; must directly follow the matching forward_train (same workspace, same train buffer)."""
+        names; must directly follow the matching forward_train (same workspace, same train buffer).  With h0 (the
+        tensor forward_train saw) the result also holds its gradient (L, B, N, H) under HotPath.D_H0."""
         s = self.spec
-        x = _check_tensor(x, "X", (self.batch, s.x_steps, s.nodes, s.x_feat))
+        xp, src, _keep = self._source(x)
         d_out = _check_tensor(d_out, "d_out", (self.batch, s.out_window, s.nodes, s.out_dim))
         drop_mask = self._mask(drop_mask)
+        h0 = self._h0(h0)
+        d_h0 = torch.empty_like(h0) if h0 is not None else None
         grads: Dict[str, torch.Tensor] = {}
         g = _lib.Params()
+        views = self._grad_views(state)
 
         def new(name):
-            t = torch.empty_like(state[name], memory_format=torch.contiguous_format)
-            grads[name] = t
-            return t.data_ptr()
+            grads[name] = views[name]
+            return views[name].data_ptr()
 
         if not s.gcn_off:
             if state["node_emb"].requires_grad or not isinstance(state["node_emb"], torch.nn.Parameter):
@@ -386,19 +472,25 @@ class HotPath:
                 for nm in ("gate", "update"):
                     grads["encoder.agru_cells.%d.%s.weights_g" % (l, nm)].zero_()
         for name, t in state.items():    # tensors the forward never reads (unused heads, node_vec* without
+            if name.startswith("static_initial"):   # host-side torch layers (MultiATGCN.py:288-290, 336-338): not ours
+                continue
             if name not in grads and (t.requires_grad or not isinstance(t, torch.nn.Parameter)):   # adaptive adjacency)
-                grads[name] = torch.zeros_like(t)
+                grads[name] = views[name].zero_()
         tr = self._train_buffer()
         ws, wsb = self._ws()
         _lib.check(self.lib.matgcn_backward(C.byref(self.dims), C.byref(self.params),
-                                            C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
-                                            C.c_void_p(_ptr(drop_mask)),
-                                            C.c_void_p(d_out.data_ptr()), C.byref(g), ws, wsb,
+                                            C.c_void_p(self.prepared.data_ptr()), C.c_void_p(xp),
+                                            C.byref(src) if src is not None else None,
+                                            C.c_void_p(_ptr(h0)), C.c_void_p(_ptr(drop_mask)),
+                                            C.c_void_p(d_out.data_ptr()), C.byref(g), C.c_void_p(_ptr(d_h0)), ws, wsb,
                                             C.c_void_p(tr.data_ptr()), C.c_size_t(tr.numel() * 4), self._stream()),
                    "matgcn_backward")
+        if d_h0 is not None:
+            grads[self.D_H0] = d_h0
         return grads
 
-    def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps) -> torch.Tensor:
+    def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps,
+                       h0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Forward fed from the device-resident series (T, N, F): sample b's window rows are gathered by the
         head-fusion prologue from series[label_start[b] + rel_steps[s]] (multistgraph_amd/windows.py)."""
         s = self.spec
@@ -410,6 +502,7 @@ class HotPath:
         rel = [int(v) for v in rel_steps]
         if len(rel) != s.x_steps:
             raise _lib.MatgcnError("rel_steps has %d entries, x_steps is %d" % (len(rel), s.x_steps))
+        h0 = self._h0(h0)
         self._need_prepared()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
         ws, wsb = self._ws()
@@ -417,7 +510,7 @@ class HotPath:
         _lib.check(self.lib.matgcn_forward_series(
             C.byref(self.dims), C.byref(self.params), C.c_void_p(self.prepared.data_ptr()),
             C.c_void_p(series.data_ptr()), C.c_int64(series.shape[0]), C.c_void_p(label_start.contiguous().data_ptr()),
-            rel_c, C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward_series")
+            rel_c, C.c_void_p(_ptr(h0)), C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward_series")
         return out
 
     def fuse_heads(self, x: torch.Tensor) -> torch.Tensor:

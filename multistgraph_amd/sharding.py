@@ -77,6 +77,14 @@ def flat_allreduce_mean_(tensors: Sequence[torch.Tensor], group=None) -> None:
         off += n
 
 
+def bucket_allreduce_mean_(bucket: torch.Tensor, group=None) -> None:
+    """In-place mean over ranks of the flat gradient buffer itself (HotPath.grad_bucket / MultiATGCN.gradient_bucket):
+    the parameters' ``.grad`` are views of it, so this ONE collective on ONE tensor is the whole gradient exchange - no
+    concatenation, no copy back."""
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    bucket /= dist.get_world_size(group)
+
+
 def replicas_in_sync(params: Iterable[torch.Tensor], group=None, device=None) -> bool:
     """True when every rank holds bit-identical parameters (checksum all-reduce MIN/MAX).  ``device``: where the
     two checksums travel (a GPU for the nccl/RCCL backend, None = CPU for gloo)."""

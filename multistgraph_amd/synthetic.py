@@ -161,7 +161,7 @@ def param_shapes(n: int, *, out_steps: int, hidden: int = 64, layers: int = 2,
                  embed_dim_node: int = 20, embed_dim_adj: int = 20, feat_in: int = 2,
                  out_dim: int = 1, k_total: int = 5, len_ts: int = 4, in_steps: int = 24,
                  adj_rank: int | None = None, gcn_off: bool = False, fnn_off: bool = False,
-                 node_specific_off: bool = False) -> dict:
+                 node_specific_off: bool = False, static: bool = False) -> dict:
     """The checkpoint ABI of the reference model (MultiATGCN.py:285-344), including the
     ablation switches: gcn_off puts dense GRU cells into encoder.agru_cells and drops res_cells (:177-192),
     fnn_off convolves the last step only (:342-344), node_specific_off shrinks the node embedding to 1 (:350-354)."""
@@ -173,8 +173,15 @@ def param_shapes(n: int, *, out_steps: int, hidden: int = 64, layers: int = 2,
         "node_vec2": (r, n),
         "weight_tsg": (len_ts,),
     }
+    q = min(n, embed_dim_node)   # PCA components of the static table (:289,:291)
+    if static:   # registered before node_emb, kept in the state_dict although forward never uses it (:288-290)
+        shapes["static_initial_node.embd.weight"] = (embed_dim_node, q)
+        shapes["static_initial_node.embd.bias"] = (embed_dim_node,)
     for i in range(len_ts):
         shapes["weight_ts.%d" % i] = (1, 24, n, out_dim)
+    if static:   # (:336-338)
+        shapes["static_initial_gru.embd.weight"] = (hidden, q)
+        shapes["static_initial_gru.embd.bias"] = (hidden,)
     shapes["encoder.weights_gru"] = (layers, in_steps)
     for l in range(layers):
         cin = (feat_in if l == 0 else hidden) + hidden

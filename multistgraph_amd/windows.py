@@ -52,3 +52,35 @@ def gather_windows(series: np.ndarray, starts: np.ndarray, rel: np.ndarray, outp
     x = series[idx]
     y = series[starts[:, None].astype(np.int64) + np.arange(output_window)[None, :]]
     return x, y
+
+
+def split_samples(num_samples: int, train_rate: float = 0.7, eval_rate: float = 0.15) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Sample indices of the train / validation / test parts exactly as TrafficStateDataset._split_train_val_test cuts
+    them (libcity/data/dataset/traffic_state_datatset.py:823-834): python round() (banker's rounding) of the test and
+    train shares, validation = the rest, test = the LAST num_test samples - written ``x[-num_test:]`` in the
+    reference, which is the WHOLE array when num_test rounds to 0; restated as written."""
+    test_rate = 1 - train_rate - eval_rate
+    num_test = round(num_samples * test_rate)
+    num_train = round(num_samples * train_rate)
+    num_val = num_samples - num_test - num_train
+    idx = np.arange(num_samples, dtype=np.int64)
+    return idx[:num_train], idx[num_train:num_train + num_val], idx[-num_test:]
+
+
+def pad_with_last_sample(indices: np.ndarray, batch_size: int) -> np.ndarray:
+    """Repeat the last sample until the part is a whole number of batches (libcity/data/utils.py:53-61; MTHDataset.json
+    sets pad_with_last_sample = true), so that every batch has exactly batch_size samples."""
+    indices = np.asarray(indices)
+    num_padding = (batch_size - (len(indices) % batch_size)) % batch_size
+    return np.concatenate([indices, np.repeat(indices[-1:], num_padding, axis=0)], axis=0)
+
+
+def epoch_batches(label_starts: np.ndarray, part: np.ndarray, batch_size: int, shuffle: bool = False,
+                  rng: np.random.Generator = None) -> np.ndarray:
+    """(batches, batch_size) int32 label starts of one epoch over a part of the samples: the part padded with its
+    last sample (the reference pads BEFORE the DataLoader shuffles, data/utils.py:53-74), optionally permuted, cut
+    into batches.  A batch on the device is just one row of this table (matgcn_forward_series)."""
+    padded = pad_with_last_sample(np.asarray(part), batch_size)
+    if shuffle:
+        padded = padded[(rng or np.random.default_rng()).permutation(len(padded))]
+    return np.asarray(label_starts)[padded].astype(np.int32).reshape(-1, batch_size)

@@ -291,14 +291,24 @@ def output_head(seq: Tensor, p, out_window: int, out_dim: int) -> Tensor:
     return conv.permute(0, 2, 1).reshape(b, out_window, out_dim, n).permute(0, 1, 3, 2)
 
 
+def static_initial_state(static: Tensor, v: Tensor, p: Dict[str, Tensor]) -> Tensor:
+    """(N, H) initial state from static features: relu(Linear(static @ v)) with v the PCA basis the reference draws with
+    torch.pca_lowrank inside forward (MultiATGCN.py:336-338, 406-408).  The PCA itself is randomised in the reference;
+    the fixtures record the v it drew (tests/golden/make_golden.py)."""
+    return F.relu(F.linear(static @ v, p["static_initial_gru.embd.weight"], p["static_initial_gru.embd.bias"]))
+
+
 def forward(xb: Tensor, p: Dict[str, Tensor], statics: Sequence[Tensor], cfg: dict,
-            faithful: bool = True, return_stages: bool = False):
-    """MultiATGCN.forward (MultiATGCN.py:363-420) with add_static=False (zero initial state)."""
+            faithful: bool = True, return_stages: bool = False, h0: Optional[Tensor] = None):
+    """MultiATGCN.forward (MultiATGCN.py:363-420).  h0 (N, H): the static-feature initial state of every layer and
+    sample (``init_state = static_embedding.expand(L, B, -1, -1)``, :409); None = the zero state of init_hidden."""
     adjtype, adpadj = cfg["adjtype"], cfg["adpadj"]
     cheb_k, layers, hid = cfg.get("cheb_order", 2), cfg.get("num_layers", 2), cfg.get("rnn_units", 64)
     x0 = fuse_heads(xb, p, cfg)
     bsz, _, n, _ = x0.shape
     init = torch.zeros(layers, bsz, n, hid, dtype=x0.dtype)
+    if h0 is not None:
+        init = h0.expand(layers, bsz, -1, -1)
     seq, finals = encoder(x0, init, p, statics, adjtype, adpadj, cheb_k, layers, faithful,
                           cfg.get("gcn_off", False))
     if cfg.get("fnn_off", False):
@@ -329,10 +339,10 @@ def masked_mae(pred: Tensor, label: Tensor, null_val=float("nan"), min_s: float 
     return loss.mean()
 
 
-def calculate_loss(xb: Tensor, yb: Tensor, p, statics, cfg, mean=0.0, std=1.0, faithful=True):
+def calculate_loss(xb: Tensor, yb: Tensor, p, statics, cfg, mean=0.0, std=1.0, faithful=True, h0=None):
     """MultiATGCN.calculate_loss (MultiATGCN.py:422-427): de-scale both, masked MAE, null 0."""
     s0, s1 = cfg.get("start_dim", 0), cfg.get("end_dim", 1)
-    pred = forward(xb, p, statics, cfg, faithful) * std + mean
+    pred = forward(xb, p, statics, cfg, faithful, h0=h0) * std + mean
     true = yb[..., s0:s1] * std + mean
     return masked_mae(pred, true, 0.0)
 

@@ -47,8 +47,39 @@ def build_reference(case):
     return model, df, cfg, state
 
 
+class pinned_pca:
+    """The reference draws a fresh randomised PCA basis with torch.pca_lowrank inside EVERY forward (MultiATGCN.py:407).
+    To make its outputs reproducible elsewhere, the basis v of one real call (seeded) is recorded and replayed for
+    every forward made under this context; the fixture stores that v."""
+
+    def __init__(self, model, seed):
+        self.v = None
+        if model.static is not None:
+            torch.manual_seed(seed + 4242)
+            _, _, self.v = torch.pca_lowrank(model.static, q=min(model.num_nodes, model.embed_dim_node))
+        self.real = torch.pca_lowrank
+
+    def __enter__(self):
+        if self.v is not None:
+            torch.pca_lowrank = lambda A, q=None, center=True, niter=2: (None, None, self.v)
+        return self
+
+    def __exit__(self, *exc):
+        torch.pca_lowrank = self.real
+
+
 def run_case(case):
     model, df, cfg, state = build_reference(case)
+    with pinned_pca(model, case["seed"]) as pca:
+        out = _run_case(case, model, df, cfg, state)
+        if pca.v is not None:
+            out["pca_v"] = pca.v.numpy()
+            with torch.no_grad():   # the (N, H) initial state every layer and sample starts from (:406-409)
+                out["h0"] = model.static_initial_gru(torch.matmul(model.static, pca.v)).numpy()
+    return out
+
+
+def _run_case(case, model, df, cfg, state):
     n, b = case["nodes"], case["batch"]
     x, y = syn.make_batch_arrays(b, n, case["out"], case["seed"], feat=case["feat"])
     xb, yb = torch.from_numpy(x), torch.from_numpy(y)
@@ -145,6 +176,12 @@ for (adjt, adp) in [("multi", "unidirection"), ("multi", "bidirection"), ("multi
                     ("od", "none"), ("identity", "none")]:
     CASES.append(dict(name="tiny_%s_%s_c1" % (adjt, adp[:3]), nodes=21, batch=2, out=3, feat=2, adjtype=adjt,
                       adpadj=adp, cheb=1, seed=10, stages=True))
+# add_static (MultiATGCN.py:244-250,286-296,335-338,406-409): static features give the 1/euclid similarity adjacency
+# (a dense third support), static_initial_node / static_initial_gru, and the encoder's initial state
+CASES.append(dict(name="tiny_multi_uni_c2_static", nodes=21, batch=2, out=3, feat=2, adjtype="multi",
+                  adpadj="unidirection", cheb=2, seed=10, stages=True, static_dim=24))
+CASES.append(dict(name="tiny_cosine_non_c3_static", nodes=21, batch=3, out=6, feat=2, adjtype="cosine",
+                  adpadj="none", cheb=3, seed=100, stages=True, static_dim=30))
 CASES.append(dict(name="tiny_multi_uni_out12", nodes=21, batch=3, out=12, feat=2, adjtype="multi",
                   adpadj="unidirection", cheb=2, seed=100, stages=True))
 CASES.append(dict(name="tiny_multi_uni_dyn7", nodes=19, batch=2, out=6, feat=7, adjtype="multi",

@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (imports the reference)
 
 NAMES = ["tiny_multi_uni_c2", "tiny_multi_bid_c2", "tiny_od_non_c2", "tiny_multi_uni_dyn7", "tiny_multi_uni_c1",
-         "tiny_identity_non_c1"]
+         "tiny_identity_non_c1", "tiny_multi_uni_c2_static", "tiny_cosine_non_c3_static"]
 SUB = 17
 
 
@@ -49,8 +49,9 @@ def run(case):
     mg.REF.F.dropout = fixed_dropout
     model.predict = spy
     try:
-        loss = model.calculate_loss({"X": torch.from_numpy(x), "y": torch.from_numpy(y).clone()})
-        loss.backward()
+        with mg.pinned_pca(model, case["seed"]):     # the same basis v the forward fixture stores
+            loss = model.calculate_loss({"X": torch.from_numpy(x), "y": torch.from_numpy(y).clone()})
+            loss.backward()
     finally:
         mg.REF.F.dropout = real_dropout
     out = {"drop_bits": np.packbits(mask > 0), "drop_shape": np.array(mask.shape), "loss": np.float64(loss.item()),

@@ -48,6 +48,27 @@ def main():
         for k, v in c.items():
             out[tag + "_" + k] = np.int64(v)
         print(tag, "samples", src.shape, "starts", starts[0], "..", starts[-1])
+    # train / validation / test split and last-sample padding, by the reference's own functions on index arrays
+    # (traffic_state_datatset.py:806-834, data/utils.py:32-79); 40 samples at 0.98 / 0.01 makes num_test round to 0
+    from libcity.data.dataset.traffic_state_datatset import TrafficStateDataset
+    from libcity.data.utils import generate_dataloader
+    split_cases = [(2905, 0.7, 0.15), (3577, 0.7, 0.15), (1000, 0.6, 0.2), (37, 0.7, 0.15), (40, 0.98, 0.01), (10, 0.5, 0.25)]
+    out["split_cases"] = np.asarray(split_cases, dtype=np.float64)
+    for i, (ns, tr, ev) in enumerate(split_cases):
+        stub = types.SimpleNamespace(train_rate=tr, eval_rate=ev, cache_dataset=False, _logger=logging.getLogger("golden"))
+        ids = np.arange(ns, dtype=np.int64)[:, None]
+        xt, _, xv, _, xs, _ = TrafficStateDataset._split_train_val_test(stub, ids, ids.copy())
+        out["split%d_train" % i], out["split%d_val" % i], out["split%d_test" % i] = xt[:, 0], xv[:, 0], xs[:, 0]
+        print("split", ns, tr, ev, "->", len(xt), len(xv), len(xs))
+    pad_cases = [(2034, 64), (436, 64), (435, 64), (128, 64), (5, 8), (1, 4)]
+    out["pad_cases"] = np.asarray(pad_cases, dtype=np.int64)
+    for i, (ns, bs) in enumerate(pad_cases):
+        ids = np.arange(ns, dtype=np.int64)[:, None]
+        dl_train, dl_eval, dl_test = generate_dataloader(ids, ids[: max(1, ns // 3)], ids[: max(1, ns // 2)], {"X": "float"}, bs, 0,
+                                                         shuffle=False, pad_with_last_sample=True)
+        out["pad%d_train" % i] = np.asarray(dl_train.dataset.data)[:, 0]
+        out["pad%d_eval" % i] = np.asarray(dl_eval.dataset.data)[:, 0]
+        out["pad%d_test" % i] = np.asarray(dl_test.dataset.data)[:, 0]
     np.savez_compressed(os.path.join(HERE, "windows_small.npz"), **out)
 
 

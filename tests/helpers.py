@@ -26,9 +26,12 @@ class Case:
         self.adjtype, self.adpadj, self.cheb, self.seed = m["adjtype"], m["adpadj"], m["cheb"], m["seed"]
         self.flags = dict(m.get("flags", {}))
         self.k_total = syn.k_total_for(self.adjtype, self.adpadj, self.cheb)
-        self.data_feature = syn.make_data_feature(self.n, self.seed, m.get("city", "DC"), ext_dim=self.feat - 1)
+        self.static_dim = m.get("static_dim", 0)
+        self.data_feature = syn.make_data_feature(self.n, self.seed, m.get("city", "DC"), ext_dim=self.feat - 1,
+                                                  static_dim=self.static_dim)
+        self.static = self.data_feature["static"]
         self.shapes = syn.param_shapes(self.n, out_steps=self.out, feat_in=self.feat, k_total=self.k_total,
-                                       **self.flags)
+                                       static=self.static_dim > 0, **self.flags)
         self.state = syn.closed_form_state(self.shapes, self.seed)
         self.x, self.y = syn.make_batch_arrays(self.b, self.n, self.out, self.seed, feat=self.feat)
 
@@ -43,6 +46,13 @@ class Case:
                     len_closeness=48, len_period=24, len_trend=24, output_window=self.out, input_window=24,
                     add_time_in_day=True, add_day_in_week=False, load_dynamic=self.feat > 2, start_dim=0,
                     end_dim=1, **self.flags)
+
+    def h0(self, layers=2, batch=None):
+        """(L, B, N, H) initial state of the static-feature cases as the reference computed it, else None"""
+        if self.static_dim == 0:
+            return None
+        e = torch.from_numpy(self.gold["h0"])
+        return e.expand(layers, self.b if batch is None else batch, -1, -1).contiguous()
 
     def checksums_ok(self):
         xs = float(self.x.astype(np.float64).sum())

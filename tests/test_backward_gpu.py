@@ -32,15 +32,32 @@ def _path(c, fold=True):
     return hp, dev, state
 
 
+D_H0 = "__d_h0__"
+
+
 def _oracle_grads(c, d_out):
-    """d(sum(out * d_out))/d(param) by autograd through the oracle in fp64."""
+    """d(sum(out * d_out))/d(param) by autograd through the oracle in fp64.  Static-feature cases: the initial state
+    (L, B, N, H) is a leaf of its own (key D_H0) - what the C ABI returns; the host-side static_initial_* layers are
+    not the HIP path's business and are left out."""
     from oracle import matgcn_oracle as orc
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in c.state.items()}
     use_static = c.adpadj == "none" or c.adjtype == "multi"
     statics = orc.supports_as_tensors(c.gold["static_supports"], torch.float64) if use_static else []
-    y = orc.forward(torch.tensor(c.x, dtype=torch.float64), p, statics, c.oracle_cfg(), faithful=False)
+    h0 = c.h0()
+    cfg = c.oracle_cfg()
+    if h0 is None:
+        y = orc.forward(torch.tensor(c.x, dtype=torch.float64), p, statics, cfg, faithful=False)
+    else:
+        h0 = h0.double().requires_grad_(True)
+        x0 = orc.fuse_heads(torch.tensor(c.x, dtype=torch.float64), p, cfg)
+        seq, _ = orc.encoder(x0, h0, p, statics, cfg["adjtype"], cfg["adpadj"], cfg["cheb_order"], 2, faithful=False)
+        y = orc.output_head(seq, p, c.out, 1)
     (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
-    return y.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in p.items()}
+    want = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in p.items()
+            if not k.startswith("static_initial")}
+    if h0 is not None:
+        want[D_H0] = h0.grad.numpy()
+    return y.detach().numpy(), want
 
 
 def _reference_gemm(a, b, c, desc, alpha, beta):
@@ -116,11 +133,13 @@ def test_backward_matches_oracle_autograd(name, fold, lib_built):
     d_out = rng.standard_normal((c.b, c.out, c.n, 1)).astype(np.float32)
     want_y, want = _oracle_grads(c, d_out)
     x = torch.from_numpy(c.x).to(dev)
-    y = hp.forward_train(x)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
+    y = hp.forward_train(x, None, h0)
     assert max_norm_err(y.cpu().numpy(), want_y) <= 1e-4
-    assert torch.equal(y, hp.forward(x))                       # the saving instantiations compute the same forward
-    hp.forward_train(x)
-    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state)
+    assert torch.equal(y, hp.forward(x, h0))                   # the saving instantiations compute the same forward
+    hp.forward_train(x, None, h0)
+    grads = hp.backward(x, torch.from_numpy(d_out).to(dev), state, None, h0)
     torch.cuda.synchronize()
     assert set(grads) == set(want)
     worst = {}
@@ -171,14 +190,26 @@ def test_backward_matches_reference_autograd(name, lib_built):
     hp, dev, state = _path(c)
     x = torch.from_numpy(c.x).to(dev)
     mask = torch.from_numpy(_fixture_mask(gold)).to(dev)
-    y = hp.forward_train(x, mask)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
+    y = hp.forward_train(x, mask, h0)
     assert max_norm_err(y.cpu().numpy(), gold["pred"]) <= 1e-4
-    grads = hp.backward(x, torch.from_numpy(gold["d_out"]).to(dev), state, mask)
+    grads = hp.backward(x, torch.from_numpy(gold["d_out"]).to(dev), state, mask, h0)
+    d_h0 = grads.pop(D_H0, None)
+    if d_h0 is not None:
+        # the reference's gradients of static_initial_gru.embd.* are d_h0 pushed through expand + ReLU + nn.Linear:
+        # redo those three host-side steps in torch and compare with the fixture
+        w = torch.tensor(c.state["static_initial_gru.embd.weight"], dtype=torch.float64, requires_grad=True)
+        bvec = torch.tensor(c.state["static_initial_gru.embd.bias"], dtype=torch.float64, requires_grad=True)
+        z = torch.tensor(c.static, dtype=torch.float64) @ torch.tensor(c.gold["pca_v"], dtype=torch.float64)
+        emb = torch.relu(torch.nn.functional.linear(z, w, bvec))
+        emb.expand(2, c.b, -1, -1).backward(d_h0.double().cpu())
+        grads["static_initial_gru.embd.weight"], grads["static_initial_gru.embd.bias"] = w.grad, bvec.grad
     bad = _check_against_fixture(gold, grads)
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", GRAD_CASES[:2])
+@pytest.mark.parametrize("name", ["tiny_multi_bid_c2", "tiny_multi_uni_c2", "tiny_multi_uni_c1"])
 def test_plugin_training_step(name, lib_built, monkeypatch):
     """the plugin surface as TrafficStateExecutor._train_epoch drives it (traffic_state_executor.py:411-422):
     model.train(); loss = model.calculate_loss(batch); loss.backward() -> p.grad of every parameter"""
@@ -211,6 +242,73 @@ def test_plugin_training_step(name, lib_built, monkeypatch):
     opt.step()
     l3 = model.calculate_loss(batch)
     assert float(l3) < float(l2)
+
+
+def test_gradient_bucket_views_accumulation_and_zeroing(lib_built, monkeypatch):
+    """Every HIP-path gradient is a view of ONE flat buffer (one all-reduce in data-parallel training, no copy); the
+    buffer is reused from step to step, but never while a parameter's .grad still lives in it: gradient accumulation
+    and zero_grad(set_to_none=False) must give the same numbers as with separate tensors."""
+    from multistgraph_amd.model import MultiATGCN
+    c = Case("tiny_multi_uni_c2")
+    dev = torch.device("cuda:0")
+    model = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+    model.train()
+    monkeypatch.setattr(torch.nn.functional, "dropout", lambda inp, p=0.5, training=True, inplace=False: inp)
+    batch = {"X": torch.from_numpy(c.x).to(dev), "y": torch.from_numpy(c.y).to(dev)}
+    model.calculate_loss(batch).backward()
+    bucket = model.gradient_bucket()
+    assert bucket is not None and bucket.dim() == 1
+    lo, hi = bucket.data_ptr(), bucket.data_ptr() + bucket.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+    first = {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    def close(a, b):
+        return float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
+
+    model.calculate_loss(batch).backward()                      # accumulate: .grad still lives in the bucket
+    assert all(close(p.grad, 2 * first[k]) for k, p in model.named_parameters())
+    for p in model.parameters():
+        p.grad.zero_()                                          # zero_grad(set_to_none=False)
+    model.calculate_loss(batch).backward()
+    assert all(close(p.grad, first[k]) for k, p in model.named_parameters())
+    for p in model.parameters():
+        p.grad = None                                           # zero_grad() of torch 2: the bucket is reused
+    model.calculate_loss(batch).backward()
+    again = model.gradient_bucket()
+    assert again is not None and again.data_ptr() == bucket.data_ptr()
+    assert all(close(p.grad, first[k]) for k, p in model.named_parameters())
+
+
+def test_plugin_training_step_with_static_features(lib_built, monkeypatch):
+    """add_static through the plugin surface (MultiATGCN.py:244-250,286-296,335-338,406-409): the randomised
+    torch.pca_lowrank of the reference's forward is replayed from the fixture's recorded basis; loss and the gradient
+    of EVERY parameter - static_initial_gru.embd.* through the HIP backward's d_h0 included - against the reference's
+    own training step; static_initial_node gets none (forward never uses it)."""
+    from multistgraph_amd.model import MultiATGCN
+    name = "tiny_multi_uni_c2_static"
+    c = Case(name)
+    gold = np.load(os.path.join(GOLDEN_DIR, "grad_%s.npz" % name))
+    dev = torch.device("cuda:0")
+    model = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+    assert model.static.device.type == "cuda"                       # the buffer follows model.to(device)
+    v = torch.from_numpy(c.gold["pca_v"]).to(dev)
+    monkeypatch.setattr(torch, "pca_lowrank", lambda A, q=None, center=True, niter=2: (None, None, v))
+    batch = {"X": torch.from_numpy(c.x).to(dev), "y": torch.from_numpy(c.y).to(dev)}
+    model.eval()
+    with torch.no_grad():
+        assert max_norm_err(model.predict(batch).cpu().numpy(), c.gold["pred"]) <= 1e-4
+    model.train()
+    mask = torch.from_numpy(_fixture_mask(gold)).to(dev)
+    monkeypatch.setattr(torch.nn.functional, "dropout", lambda inp, p=0.5, training=True, inplace=False: inp * mask)
+    loss = model.calculate_loss(batch)
+    assert abs(float(loss) - float(gold["loss"])) <= 1e-4 * abs(float(gold["loss"]))
+    loss.backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+    assert float(grads["static_initial_gru.embd.weight"].abs().max()) > 0
+    bad = _check_against_fixture(gold, grads)
+    assert not bad, bad
 
 
 def test_dropout_mask_of_the_last_step_head(lib_built):

@@ -13,11 +13,11 @@ from helpers import FULL, TINY, Case
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", TINY[:6] + FULL[:2])
+@pytest.mark.parametrize("name", TINY[:6] + FULL[:2] + ["tiny_multi_uni_c2_static", "tiny_cosine_non_c3_static"])
 def test_graph_prep_matches_reference(name):
     from multistgraph_amd import graph_prep
     c = Case(name)
-    mats = graph_prep.build_static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], None, c.adjtype)
+    mats = graph_prep.build_static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], c.static, c.adjtype)
     assert np.abs(np.stack(mats, 0) - c.gold["static_supports"]).max() <= 1e-6
 
 
@@ -33,7 +33,8 @@ def test_graph_prep_unsorted_geo_ids():
 
 
 @pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_od_non_c3", "tiny_multi_non_c3", "tiny_multi_uni_dyn7",
-                                  "dc237_out12", "abl_gcnoff", "abl_fnnoff", "abl_nodeoff", "abl_gcnfnnoff"])
+                                  "dc237_out12", "abl_gcnoff", "abl_fnnoff", "abl_nodeoff", "abl_gcnfnnoff",
+                                  "tiny_multi_uni_c1", "tiny_multi_uni_c2_static", "tiny_cosine_non_c3_static"])
 def test_parameter_tree_is_the_checkpoint_abi(name):
     from multistgraph_amd.model import MultiATGCN
     c = Case(name)
@@ -71,9 +72,6 @@ def test_unsupported_options_fail_loudly():
     from multistgraph_amd import synthetic as syn
     from multistgraph_amd.model import MultiATGCN
     c = Case("tiny_multi_uni_c2")
-    df = dict(c.data_feature, static=syn.make_static(c.n, 5, 0))
-    with pytest.raises(NotImplementedError):
-        MultiATGCN(c.config(), df)
     m = MultiATGCN(c.config(), c.data_feature).eval()
     with torch.no_grad(), pytest.raises(RuntimeError):
         m.predict({"X": torch.from_numpy(c.x)})      # CPU tensor: no fallback
@@ -142,8 +140,10 @@ def test_training_entry_points_check_their_arguments(lib_built):
     assert lib.matgcn_train_bytes(C.byref(d1), C.byref(nb1)) == 0 and nb1.value < nb.value / 10
     assert lib.matgcn_train_bytes(C.byref(d), None) == -1
     p = _lib.Params()
-    assert lib.matgcn_forward_train(C.byref(d), C.byref(p), None, None, None, None, None, 0, None, 0, None) == -1
-    assert lib.matgcn_backward(C.byref(d), C.byref(p), None, None, None, None, C.byref(p), None, 0, None, 0, None) == -1
+    assert lib.matgcn_forward_train(C.byref(d), C.byref(p), None, None, None, None, None, None, None, 0, None, 0,
+                                    None) == -1
+    assert lib.matgcn_backward(C.byref(d), C.byref(p), None, None, None, None, None, None, C.byref(p), None, None, 0,
+                               None, 0, None) == -1
     assert lib.matgcn_debug_gemm(None, None, None, None, 1.0, 0.0, None) == -1
 
 
@@ -166,6 +166,7 @@ def _reference_model_class():
     ("tiny_multi_uni_c2", {}), ("tiny_od_non_c3", {}), ("tiny_multi_bid_c2", {}), ("tiny_multi_uni_dyn7", {}),
     ("abl_gcnoff", {}), ("abl_fnnoff", {}), ("abl_nodeoff", {}), ("abl_gcnfnnoff", {}),
     ("tiny_multi_uni_c2", {"cheb_order": 1}), ("tiny_od_non_c2", {"cheb_order": 1}),
+    ("tiny_multi_uni_c2", {"static_dim": 24}), ("tiny_cosine_non_c2", {"static_dim": 30}),
 ])
 def test_same_seed_gives_the_reference_initial_weights(name, extra):
     """_init_parameters (MultiATGCN.py:356-361) AND the RNG stream in front of it (:296 randn,

@@ -15,6 +15,13 @@ from oracle import matgcn_oracle as O
 TOL = 1e-5
 
 
+def _static_h0(c, p, dtype=torch.float32):
+    """initial state of the static-feature cases from the fixture's PCA basis (None for the others)"""
+    if c.static_dim == 0:
+        return None
+    return O.static_initial_state(torch.as_tensor(c.static).to(dtype), torch.as_tensor(c.gold["pca_v"]).to(dtype), p)
+
+
 @pytest.mark.parametrize("name", TINY + FULL)
 def test_inputs_regenerate_identically(name):
     assert Case(name).checksums_ok()
@@ -23,7 +30,7 @@ def test_inputs_regenerate_identically(name):
 @pytest.mark.parametrize("name", TINY + FULL)
 def test_static_supports(name):
     c = Case(name)
-    mats = O.static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], None, c.adjtype)
+    mats = O.static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], c.static, c.adjtype)
     got = np.stack(mats, 0)
     assert got.shape == c.gold["static_supports"].shape
     assert np.abs(got - c.gold["static_supports"]).max() <= 1e-6
@@ -68,11 +75,16 @@ def test_stages_tiny(name):
     assert max_norm_err(h2.numpy(), g["cell_l1"]) <= TOL
     r = O.dense_gru_cell(xs, hs, p, "encoder.res_cells.0.")
     assert max_norm_err(r.numpy(), g["res_l0"]) <= TOL
+    h0 = _static_h0(c, p)
+    if h0 is not None:      # the (N, H) initial state itself: relu(Linear(static @ v)) with the recorded PCA basis
+        assert max_norm_err(h0.numpy(), g["h0"]) <= TOL
     for faithful in (True, False):
-        pred, stg = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful, True)
+        # the encoder stages of the fixtures start from the zero state (init_hidden), the prediction from h0
+        _, stg = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful, True)
         assert max_norm_err(stg["x0"].numpy(), g["x0"]) <= TOL
         assert max_norm_err(stg["seq"].numpy(), g["enc_seq"]) <= TOL
         assert max_norm_err(stg["finals"].numpy(), g["enc_finals"]) <= TOL
+        pred = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful, h0=h0)
         assert max_norm_err(pred.numpy(), g["pred"]) <= TOL
     del use_static
 
@@ -83,10 +95,11 @@ def test_prediction_loss_and_mae(name):
     g = c.gold
     p = O.to_tensors(c.state)
     st = O.supports_as_tensors(g["static_supports"])
-    pred = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful=False)
+    h0 = _static_h0(c, p)
+    pred = O.forward(torch.from_numpy(c.x), p, st, c.oracle_cfg(), faithful=False, h0=h0)
     assert pred.shape == g["pred"].shape
     assert max_norm_err(pred.numpy(), g["pred"]) <= TOL
-    loss = O.calculate_loss(torch.from_numpy(c.x), torch.from_numpy(c.y), p, st, c.oracle_cfg(), faithful=False)
+    loss = O.calculate_loss(torch.from_numpy(c.x), torch.from_numpy(c.y), p, st, c.oracle_cfg(), faithful=False, h0=h0)
     assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     ytrue = torch.from_numpy(c.y)[..., 0:1]
     for i in range(c.out):
@@ -122,6 +135,9 @@ def test_oracle_autograd_matches_reference_gradients(name):
     cfg = c.oracle_cfg()
     x0 = orc.fuse_heads(torch.tensor(c.x, dtype=torch.float64), p, cfg)
     init = torch.zeros(2, c.b, c.n, 64, dtype=torch.float64)
+    h0 = _static_h0(c, p, torch.float64)       # its gradient reaches static_initial_gru.embd.*
+    if h0 is not None:
+        init = h0.expand(2, c.b, -1, -1)
     seq, _ = orc.encoder(x0, init, p, statics, cfg["adjtype"], cfg["adpadj"], cfg["cheb_order"], 2, faithful=False)
     y = orc.output_head(seq * torch.tensor(mask), p, c.out, 1)
     assert max_norm_err(y.detach().numpy(), gold["pred"]) <= 1e-5

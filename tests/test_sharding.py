@@ -55,6 +55,28 @@ def _worker(rank, world, port, out_dir):
         sh.flat_allreduce_mean_([g1, None, g2])
         mean = (world + 1) / 2
         assert torch.allclose(g1, torch.full((3, 2), mean)) and torch.allclose(g2, torch.arange(4.0) * mean)
+        # the gradients as VIEWS of one flat buffer (what matgcn_backward fills): one collective on the buffer, and
+        # every parameter's .grad - adopted by autograd from those views - sees the mean without a copy back
+        bucket = torch.zeros(192)
+
+        class _Step(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a, b):
+                return (a.sum() + b.sum()) * 0.0 + 1.0
+
+            @staticmethod
+            def backward(ctx, up):
+                va, vb = bucket[0:6].view(2, 3), bucket[64:68].view(4)
+                va.fill_(float(rank + 1)); vb.copy_(torch.arange(4.0) * (rank + 1))
+                return va, vb
+
+        pa, pb = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))
+        _Step.apply(pa, pb).backward()
+        lo, hi = bucket.data_ptr(), bucket.data_ptr() + bucket.numel() * 4
+        assert lo <= pa.grad.data_ptr() < hi and lo <= pb.grad.data_ptr() < hi      # adopted, not copied
+        sh.bucket_allreduce_mean_(bucket)
+        assert torch.allclose(pa.grad, torch.full((2, 3), mean)) and torch.allclose(pb.grad, torch.arange(4.0) * mean)
+        assert float(bucket[6:64].abs().max()) == 0.0                               # alignment gaps stay zero
         # replica check
         assert sh.replicas_in_sync([torch.ones(3)])
         assert not sh.replicas_in_sync([torch.ones(3) * (rank + 1)])
