@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing (N=1 only)")
     ap.add_argument("--cache-prepared", action="store_true",
                     help="keep matgcn_prepare out of the timed steps (inference with frozen weights)")
+    ap.add_argument("--no-bf16-variant", action="store_true", help="skip the bf16-operand side line")
     ap.add_argument("--median", type=int, default=100,
                     help="forwards of the HIP-event-timed median protocol (SURVEY.md 8d; 0 = skip)")
     ap.add_argument("--median-warmup", type=int, default=20)
@@ -354,6 +355,34 @@ def main():
                   "p10_ms": ts_ms[len(ts_ms) // 10], "p90_ms": ts_ms[(len(ts_ms) * 9) // 10], "min_ms": ts_ms[0],
                   "node_steps_per_s_rank0": w["batch"] * 24 * w["nodes"] / (med * 1e-3),
                   "note": "each forward bracketed by HIP events on the caller's stream, rank 0"}
+    # BASELINE config 3's dtype as a side line: bf16 operands for the graph mixes (fp32 accumulate, fp32 state);
+    # never `value` - narrower than the reference's fp32 - and with its own error figure against the fp32 path
+    bf16_variant = None
+    if rank == 0 and not args.no_bf16_variant:
+        from multistgraph_amd import _lib
+        lib = _lib.load()
+        with torch.no_grad():
+            exact = model.predict(batch).clone()
+            prev_mode = lib.matgcn_set_mix_precision(1)
+            try:
+                for _ in range(max(3, args.warmup)):
+                    got = model.predict(batch)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    got = model.predict(batch)
+                e1.record()
+                torch.cuda.synchronize()
+            finally:
+                lib.matgcn_set_mix_precision(prev_mode)
+        bms = e0.elapsed_time(e1) / args.steps
+        bf16_variant = {"ms_per_step": bms, "node_steps_per_s_rank0": w["batch"] * 24 * w["nodes"] / (bms * 1e-3),
+                        "max_norm_err_vs_f32": float((got - exact).abs().max() / exact.abs().max()),
+                        "tolerance": 5e-3,
+                        "note": "matgcn_set_mix_precision(1): the graph mixes round their operands (support stack, state "
+                                "rows) to bf16 and run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; state, "
+                                "node-wise contractions, inputs and outputs stay fp32.  Reported beside the f32 headline, "
+                                "never as `value`"}
     units_local = w["batch"] * 24 * w["nodes"] * args.steps
     if distributed:
         from multistgraph_amd import sharding
@@ -403,6 +432,9 @@ def main():
                 continue
             t = statistics.mean(ms_list) * 1e-3
             pk = pmc_of(kind)
+            if kind == "k_px":   # a launch covers a chunk of 1-4 steps: scale the per-step model by the average chunk
+                steps_per_launch = 24.0 * (spec.layers - 1) / (len(ms_list) / 2.0)
+                models[kind] = {k: v * steps_per_launch for k, v in models[kind].items()}
             node_kernels[PMC_KERNEL_NAMES[kind]] = dict(
                 launches=len(ms_list), avg_launch_ms=t * 1e3, flops_per_launch=models[kind]["flops"],
                 algorithmic_bytes_per_launch=models[kind]["bytes"], achieved_tflops=models[kind]["flops"] / t / 1e12,
@@ -464,6 +496,8 @@ def main():
         }
         if median is not None:
             result["median"] = median
+        if bf16_variant is not None:
+            result["bf16_variant"] = bf16_variant
         if frozen_elapsed is not None:
             result["frozen_weights"] = {
                 "ms_per_step": frozen_elapsed / args.steps * 1e3,

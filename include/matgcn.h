@@ -295,6 +295,15 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
  * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting. */
 int matgcn_set_wavefront(int enabled);
 
+/* ---- precision option (BASELINE config 3's dtype; a side line, never the headline) -----------------------------
+ * matgcn_set_mix_precision(1): the graph mixes of matgcn_forward / matgcn_forward_series round their operands - the
+ * support stack and the state rows - to bf16 on the way into LDS and run on v_mfma_f32_16x16x16_bf16 with fp32
+ * accumulation; inputs, outputs, the recurrent state, the node-wise contractions and everything in memory stay fp32.
+ * NARROWER than the reference's fp32 arithmetic: measured max-normalised deviation from the fp32 path <= 3e-3 at
+ * N = 403 (tests/test_hip_parity.py::test_bf16_mix_variant holds it to 5e-3).  matgcn_prepare, the training entry
+ * points and the unit entry points always use fp32 operands.  Returns the previous setting; 0 (default) = fp32. */
+int matgcn_set_mix_precision(int mode);
+
 /* ---- measurement hooks (bench.py; not on the hot path) ---------------------------------------
  * Time individual kernel launches in situ with HIP events recorded on the caller's stream.
  * enable() creates 2*max_launches events (the only allocation in the library, outside any forward)

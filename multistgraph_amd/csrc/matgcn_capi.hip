@@ -305,6 +305,12 @@ inline Wavefront& wf_current() {
 }
 #define g_wf (wf_current())
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
+int g_mix_precision = 0;      // matgcn_set_mix_precision: 0 fp32 operands, 1 bf16 operands for the inference graph mixes
+bool g_mix_bf16_now = false;  // set for the duration of an inference forward only (MixPrecisionScope)
+struct MixPrecisionScope {
+  explicit MixPrecisionScope(bool inferenceForward) { g_mix_bf16_now = inferenceForward && g_mix_precision == 1; }
+  ~MixPrecisionScope() { g_mix_bf16_now = false; }
+};
 
 int wavefront_ready() {
   if (g_wf.ready) return MATGCN_OK;
@@ -337,8 +343,15 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   a.Np = P.Np; a.N = P.N; a.Ks = Ks; a.nK = P.Np / 16; a.nColTiles = nColTiles;
   a.nRowTiles = (int)(rup(rowsM, 64) / 64);
   ProfScope prof(stepRole ? MATGCN_PROF_MIX : MATGCN_PROF_MIX_PRE, s);
-  if (stepRole) hipLaunchKernelGGL(k_mix<1>, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_mix<0>, dim3((unsigned)(a.nRowTiles * nColTiles)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)(a.nRowTiles * nColTiles));
+  if (g_mix_bf16_now) {   // opt-in bf16-operand variant of the inference forward (fp32 accumulate, fp32 in / out)
+    if (stepRole) hipLaunchKernelGGL(k_mix_bf16<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_mix_bf16<0>, grid, dim3(256), 0, s, a);
+  } else if (stepRole) {
+    hipLaunchKernelGGL(k_mix<1>, grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_mix<0>, grid, dim3(256), 0, s, a);
+  }
   return launch_ok();
 }
 
@@ -790,6 +803,12 @@ int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* lab
   return launch_ok();
 }
 
+int matgcn_set_mix_precision(int mode) {
+  const int prev = g_mix_precision;
+  g_mix_precision = mode == 1 ? 1 : 0;
+  return prev;
+}
+
 int matgcn_set_wavefront(int mode) {
   const int prev = g_wavefront_mode;
   g_wavefront_mode = mode != 0 ? 1 : 0;
@@ -984,6 +1003,7 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   RETURN_IF(check_layer_params(dims, params));
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
+  MixPrecisionScope mixScope(true);
   RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
@@ -1013,6 +1033,7 @@ int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, 
   RETURN_IF(check_series(dims, series, series_steps, label_start, rel_steps));
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
+  MixPrecisionScope mixScope(true);
   RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps));
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);

@@ -539,6 +539,137 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// 5b. the same graph mix with bf16 OPERANDS (BASELINE config 3's dtype): fp32 accumulation, fp32 inputs and outputs
+// -------------------------------------------------------------------------------------------------
+// Opt-in variant (matgcn_set_mix_precision(1); inference only, never the headline: narrower than the reference's fp32).
+// The supports and the state stay fp32 in memory; they are rounded to bf16 (round to nearest even) on their way into
+// LDS, two consecutive reduction indices packed into one 32-bit word, so that a lane's v_mfma_f32_16x16x16_bf16
+// fragment (4 consecutive k of one row / column) is two ds_read_b32.  K-tile 32 = 16 packed rows of 64 words; packed
+// row p is rotated by 16 * ((p >> 1) & 3) words, which puts the four k-quarters of a wave on four different bank
+// quarters.  Everything else - 64 x 64 tile, 2 x 2 accumulators per wave, register prefetch two tiles ahead, XCD-aware
+// tile order, the write-through row-store epilogue - is k_mix's.
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+#define MFMA16BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned int bf16_rne(float x) {     // upper 16 bits of x, rounded to nearest even
+  const unsigned int u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint4 pack_bf16_rows(const float4& k0, const float4& k1) {   // word j = (k0[j], k1[j])
+  return make_uint4(bf16_rne(k0.x) | (bf16_rne(k1.x) << 16), bf16_rne(k0.y) | (bf16_rne(k1.y) << 16),
+                    bf16_rne(k0.z) | (bf16_rne(k1.z) << 16), bf16_rne(k0.w) | (bf16_rne(k1.w) << 16));
+}
+
+template <int ROLE>
+__global__ __launch_bounds__(256) void k_mix_bf16(MixArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned int As[2][16 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned int Bs[2][16 * 64];
+  const int id = blockIdx.x;
+  int colTile, rowTile;
+  if ((a.nColTiles & 7) == 0) {
+    const int xcd = id & 7, jj = id >> 3, cpx = a.nColTiles >> 3;
+    rowTile = jj % a.nRowTiles;
+    colTile = xcd * cpx + jj / a.nRowTiles;
+  } else {
+    rowTile = id % a.nRowTiles;
+    colTile = id / a.nRowTiles;
+  }
+  const int row0 = rowTile * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1, j = lane & 15, kq = lane >> 4;
+  const int pr = tid >> 4, sg = tid & 15;                  // staging: packed row pr (k = 2 pr, 2 pr + 1), 4-word segment sg
+  const int kLast = 16 * a.nK - 1;                         // reduction indices 0 .. Np-1 (a.nK = Np / 16)
+  const int nT = (a.nK + 1) >> 1;                          // K-tiles of 32
+  const int stPos = pr * 64 + (((sg + 4 * ((pr >> 1) & 3)) & 15) << 2);
+  const float* ap = a.St + row0 + sg * 4;
+  const float* bp = a.X + (size_t)colTile * a.xTileStride + sg * 4;
+  // loads are unconditional (row index clamped, values past the last reduction index zeroed by a select)
+  auto ld = [&](const float* base, size_t ld_, int t, float4& r0, float4& r1) {
+    const int k0 = 32 * min(t, nT - 1) + 2 * pr, k1 = k0 + 1;
+    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)min(k0, kLast) * ld_);
+    const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)min(k1, kLast) * ld_);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    r0 = k0 <= kLast ? v0 : z;
+    r1 = k1 <= kLast ? v1 : z;
+  };
+  float4 a0, a1, b0, b1, a2, a3, b2, b3;
+  ld(ap, a.ldS, 0, a0, a1); ld(bp, a.ldX, 0, b0, b1);
+  *reinterpret_cast<uint4*>(&As[0][stPos]) = pack_bf16_rows(a0, a1);
+  *reinterpret_cast<uint4*>(&Bs[0][stPos]) = pack_bf16_rows(b0, b1);
+  ld(ap, a.ldS, 1, a0, a1); ld(bp, a.ldX, 1, b0, b1);      // tile t+1 waits in (a0, a1, b0, b1) / (a2, a3, b2, b3)
+  ld(ap, a.ldS, 2, a2, a3); ld(bp, a.ldX, 2, b2, b3);
+  __syncthreads();
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // word of packed row (8 s + 2 kq + h) for row / column x: rotation 16 * kq
+  const int rotA0 = (wr * 32 + j + 16 * kq) & 63, rotA1 = (wr * 32 + 16 + j + 16 * kq) & 63;
+  const int rotB0 = (wc * 32 + j + 16 * kq) & 63, rotB1 = (wc * 32 + 16 + j + 16 * kq) & 63;
+  auto frag = [&](const unsigned int* T, int s, int rot) {
+    const unsigned int lo = T[(8 * s + 2 * kq) * 64 + rot], hi = T[(8 * s + 2 * kq + 1) * 64 + rot];
+    bf16x4_t v;
+    v[0] = (short)(lo & 0xffffu); v[1] = (short)(lo >> 16); v[2] = (short)(hi & 0xffffu); v[3] = (short)(hi >> 16);
+    return v;
+  };
+  auto mma = [&](int cur) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {      // the two 16-wide k-steps of this K-tile
+      const bf16x4_t fa0 = frag(As[cur], s, rotA0), fa1 = frag(As[cur], s, rotA1);
+      const bf16x4_t fb0 = frag(Bs[cur], s, rotB0), fb1 = frag(Bs[cur], s, rotB1);
+      acc[0][0] = MFMA16BF(fa0, fb0, acc[0][0]);
+      acc[0][1] = MFMA16BF(fa0, fb1, acc[0][1]);
+      acc[1][0] = MFMA16BF(fa1, fb0, acc[1][0]);
+      acc[1][1] = MFMA16BF(fa1, fb1, acc[1][1]);
+    }
+  };
+  for (int it = 0; it < nT; it += 2) {
+    mma(0);
+    *reinterpret_cast<uint4*>(&As[1][stPos]) = pack_bf16_rows(a0, a1);
+    *reinterpret_cast<uint4*>(&Bs[1][stPos]) = pack_bf16_rows(b0, b1);
+    ld(ap, a.ldS, it + 3, a0, a1); ld(bp, a.ldX, it + 3, b0, b1);
+    __syncthreads();
+    if (it + 1 < nT) {
+      mma(1);
+      *reinterpret_cast<uint4*>(&As[0][stPos]) = pack_bf16_rows(a2, a3);
+      *reinterpret_cast<uint4*>(&Bs[0][stPos]) = pack_bf16_rows(b2, b3);
+      ld(ap, a.ldS, it + 4, a2, a3); ld(bp, a.ldX, it + 4, b2, b3);
+      __syncthreads();
+    }
+  }
+  // epilogue: as k_mix (accumulator tile turned through LDS into 16-byte write-through row stores)
+  float* stg = reinterpret_cast<float*>(w < 2 ? &As[0][0] : &Bs[0][0]) + (w & 1) * 1024;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lrow = p * 16 + 4 * kq + e, lcol = q * 16 + j;
+        stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
+      }
+  const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lrow = u * 8 + (lane >> 3), q = lane & 7;
+    const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+    const int row = row0 + wr * 32 + lrow;
+    const int k = row / a.Np, n = row - k * a.Np;
+    if (k < a.Ks && n < a.N) {
+      const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
+      if (wt) {
+        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
+      } else {
+        *reinterpret_cast<float4*>(a.out + off) = v;
+      }
+    }
+  }
+}
+
 // =================================================================================================
 // 8. output head (MultiATGCN.py:416-418): Conv2d(T -> out*od, (1,H)) == [B*N x T*H] . [T*H x CH]
 // =================================================================================================

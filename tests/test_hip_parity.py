@@ -173,6 +173,34 @@ def test_forward(name, fold, lib_built):
     assert max_norm_err(got, c.gold["pred"]) <= E2E_TOL
 
 
+BF16_TOL = 5e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_od_non_c3", "tiny_multi_uni_c1", "tiny_multi_uni_c2_static",
+                                  "dc237_out12", "bm403_out24"])
+def test_bf16_mix_variant(name, lib_built):
+    """BASELINE config 3's dtype as an opt-in side line (matgcn_set_mix_precision(1)): bf16 OPERANDS for the graph
+    mixes, fp32 accumulation, fp32 state and node-wise contractions.  Narrower than the reference's fp32, so it has
+    its own tolerance: 5e-3 max-normalised against the reference's fp32 prediction (measured <= 3e-3); the fp32 path
+    must come back bit-identical when the option is switched off again."""
+    c = Case(name)
+    hp, dev = _path(c, lib_built)
+    x = torch.from_numpy(c.x).to(dev)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
+    exact = hp.forward(x, h0).clone()
+    prev = hp.lib.matgcn_set_mix_precision(1)
+    try:
+        got = hp.forward(x, h0).clone()
+    finally:
+        hp.lib.matgcn_set_mix_precision(prev)
+    assert not torch.equal(got, exact)                              # the variant really ran
+    err = max_norm_err(got.cpu().numpy(), c.gold["pred"])
+    assert err <= BF16_TOL, err
+    assert max_norm_err(exact.cpu().numpy(), c.gold["pred"]) <= E2E_TOL
+    assert torch.equal(hp.forward(x, h0), exact)                    # and the default is untouched afterwards
+
+
 def test_encoder_nonzero_initial_state_vs_oracle(lib_built):
     # h0 != 0 is not in the golden set: check against the oracle directly
     from oracle import matgcn_oracle as O
