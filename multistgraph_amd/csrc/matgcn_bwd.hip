@@ -31,11 +31,32 @@ void launch_bgemm(const dim3& grid, hipStream_t s, const GemmArgs& g) {
   hipLaunchKernelGGL(k_bgemm<ROLE>, grid, dim3(256), 0, s, g);
 }
 
+// the fast path of k_bgemm_tn: A unit-stride along M, B unit-stride along N, whole 64 x 64 tiles, 16-byte friendly
+bool tn_eligible(const GemmArgs& g) {
+  auto m4 = [](long v) { return (v & 3) == 0; };
+  return g.sAm == 1 && g.sBn == 1 && g.M % 64 == 0 && g.N % 64 == 0 && m4(g.sAk) && m4(g.sAk2) && m4(g.sBk) &&
+         m4(g.sBk2) && m4(g.bA1) && m4(g.bA2) && m4(g.bB1) && m4(g.bB2) &&
+         (reinterpret_cast<size_t>(g.A) & 15) == 0 && (reinterpret_cast<size_t>(g.B) & 15) == 0;
+}
+
+template <int ROLE>
+void launch_bgemm_tn(const dim3& grid, hipStream_t s, const GemmArgs& g) {
+  hipLaunchKernelGGL(k_bgemm_tn<ROLE>, grid, dim3(256), 0, s, g);
+}
+
 int gemm(const GemmArgs& g, int nb1, hipStream_t s, int role = BG_GENERIC) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K2 <= 0 || nb1 <= 0) return MATGCN_OK;
   const long gx = (g.N + 63) / 64, gy = (g.M + 63) / 64, gz = (long)nb1 * g.nb2 * g.split;
   if (gy > 65535 || gz > 65535 || (long)g.K2 * ((g.K + BG_KT - 1) / BG_KT) >= (1L << 30)) return MATGCN_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
+  if (tn_eligible(g)) {
+    switch (role) {
+      case BG_WGRAD: launch_bgemm_tn<BG_WGRAD>(grid, s, g); return launch_ok();
+      case BG_LINEAR: launch_bgemm_tn<BG_LINEAR>(grid, s, g); return launch_ok();
+      case BG_GENERIC: launch_bgemm_tn<BG_GENERIC>(grid, s, g); return launch_ok();   // matgcn_debug_gemm: the test's way in
+      default: break;
+    }
+  }
   switch (role) {
     case BG_CHAIN_DENSE: launch_bgemm<BG_CHAIN_DENSE>(grid, s, g); break;
     case BG_CHAIN_NODE: launch_bgemm<BG_CHAIN_NODE>(grid, s, g); break;
@@ -76,7 +97,9 @@ StackEntries stack_entries(const StackMap& map) {
 // dst[rows][m][i] = sum_kk StP[kk][m] * src[rows][slot 1..][kk][i]: the transposed graph mix of the dense slots of a
 // [rows][S][Np][Cc] gradient.  With 64 feature columns this is the forward's graph-mix kernel run on the plain stack
 // (reduction over (k, n), one column tile per row); narrower inputs (layer 0) take the generic GEMM.
-int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst) {
+// split: the reduction is cut by support slot - Ks times the workgroups, each with a K loop of the forward's length -
+// and slot k's partial result lands Ks-th part k of dst (parts `partStride` floats apart; the consumers add them up).
+int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst, bool split = false, long partStride = 0) {
   const Plan& P = b.c.P;
   if (P.Ks <= 0) return MATGCN_OK;
   const int S = b.c.R.S;
@@ -89,7 +112,11 @@ int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst)
     a.outFloats = outFloats < (1L << 29) ? outFloats : 0;
     a.Np = P.NpC; a.N = P.N; a.Ks = 1; a.nK = P.Ks * P.Np / 16; a.nColTiles = rows;
     a.nRowTiles = P.NpC / 64;
-    hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * rows)), dim3(256), 0, b.c.s, a);
+    if (split && P.Ks > 1) {
+      a.parts = P.Ks; a.nK = P.Np / 16;
+      a.aPartStride = (long)P.Np * P.NpC; a.xPartStride = (long)P.Np * H; a.outPartStride = partStride;
+    }
+    hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * rows), (unsigned)a.parts), dim3(256), 0, b.c.s, a);
     return launch_ok();
   }
   GemmArgs g = gemm_args(b.c.prep + P.oSt, src + (size_t)P.Np * Cc, dst, P.N, Cc, P.Ks * P.Np);
@@ -247,7 +274,7 @@ int bwd_clear(Pass& pass) {
                        rowsTB, N, Np, H);
     CHECK_LAUNCH();
   }
-  RETURN_IF(zero_async(tr + R.oMixOut, slab, s));
+  RETURN_IF(zero_async(tr + R.oMixOut, slab * (P.Ks > 1 ? P.Ks : 1), s));
   RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
   if (Np != N)
     for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
@@ -267,27 +294,30 @@ int bwd_clear(Pass& pass) {
   return MATGCN_OK;
 }
 
-// plain copies the backward GEMMs contract with: the support stack and the folded node-adaptive weights
-int bwd_plain_operands(Pass& pass) {
-  PASS_LOCALS(pass);
+// plain copies the backward GEMMs contract with: the support stack and the folded node-adaptive weights.  Parameter-only
+// work: matgcn_forward_train runs it on a side stream beside the forward (it used to open every backward: 0.8 ms on the
+// critical path), matgcn_backward finds the copies in the train buffer.
+int plain_operands(const Ctx& c, float* tr, hipStream_t s) {
+  const Plan& P = c.P;
+  const TrainPlan& R = c.R;
+  const StackMap map = build_stack_map(P, c.D, c.prm);
   if (P.Ks > 0) {  // plain copy of the support stack for the transposed mixes
-    hipLaunchKernelGGL(k_stack_plain, dim3((unsigned)((P.Ks * Np + 31) / 32), (unsigned)((P.NpC + 31) / 32)), dim3(256),
-                       0, s, c.prep + P.oSt, P.Mp, N, P.Ks * Np, P.NpC, tr + R.oStP);
+    hipLaunchKernelGGL(k_stack_plain, dim3((unsigned)((P.Ks * P.Np + 31) / 32), (unsigned)((P.NpC + 31) / 32)), dim3(256),
+                       0, s, c.prep + P.oSt, P.Mp, P.N, P.Ks * P.Np, P.NpC, tr + R.oStP);
     CHECK_LAUNCH();
   }
   // plain folded weights of both AGCNs of every layer
   for (int l = 0; l < P.L && !P.gcnOff; ++l)
     for (int part = 0; part < 2; ++part) {
-      const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
+      const matgcn_agcn_params& ap = part == 0 ? c.prm->gate[l] : c.prm->update[l];
       PlainPrep q;
       memset(&q, 0, sizeof(q));
-      q.E = prm->node_emb; q.wpool = ap.weights_pool; q.wg = D->scale_by_g ? ap.weights_g : nullptr;
+      q.E = c.prm->node_emb; q.wpool = ap.weights_pool; q.wg = c.D->scale_by_g ? ap.weights_g : nullptr;
       q.out = tr + R.oWp[l][part];
-      q.d = P.d; q.I = P.Cl[l] + H; q.O = part == 0 ? 128 : 64; q.N = N; q.S = S; q.map = map;
-      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)S * q.I * q.O), (unsigned)N), dim3(256), 0, s, q);
+      q.d = P.d; q.I = P.Cl[l] + H; q.O = part == 0 ? 128 : 64; q.N = P.N; q.S = R.S; q.map = map;
+      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)R.S * q.I * q.O), (unsigned)P.N), dim3(256), 0, s, q);
       CHECK_LAUNCH();
     }
-
   return MATGCN_OK;
 }
 
@@ -371,7 +401,7 @@ int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
       Xall = c.ws + P.oSeq[l - 1];
     }
     if (b.dH0) {   // the carry left by step 0 is the gradient of the layer's initial state
-      hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, carry[0], nullptr, nullptr,
+      hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, carry[0], nullptr, nullptr, 1, 0L,
                          b.dH0 + (size_t)l * B * N * H, B, N, Np, S);
       CHECK_LAUNCH();
     }
@@ -429,6 +459,7 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     a.dhA = DAg + at * S; a.dhMix = P.Ks > 0 ? MixOut : nullptr;
     a.dh = DH; a.dr = tr + R.oDR;
     a.B = B; a.N = N; a.Np = Np; a.S = S;
+    a.mixParts = P.Ks > 1 ? P.Ks : 1; a.mixPartStride = slab;     // the transposed mixes arrive split by slot
     const dim3 eg(blocks_for((size_t)slab));
     {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
       FusedResArgs f;
@@ -441,17 +472,17 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
       CHECK_LAUNCH();
     }
     RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
-    RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut));
+    RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut, true, slab));
     hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
     CHECK_LAUNCH();
     // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
     // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
     RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
-    RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut));   // the carry itself is formed by the next step's kernel
+    RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut, true, slab));   // the carry itself is formed by the next step's kernel
   }
   if (b.dH0) {   // what step 0 would carry into a step before it: dh + slot 0 of the gate AGCN's dA + its transposed mix
     hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, DH, DAg, P.Ks > 0 ? MixOut : nullptr,
-                       b.dH0 + (size_t)l * B * N * H, B, N, Np, S);
+                       P.Ks > 1 ? P.Ks : 1, (long)slab, b.dH0 + (size_t)l * B * N * H, B, N, Np, S);
     CHECK_LAUNCH();
   }
   return MATGCN_OK;
@@ -522,15 +553,51 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
   return MATGCN_OK;
 }
 
-// weight gradients of a graph layer (on the second stream when there is one)
-int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
+int bwd_pools_layer(Pass& pass, int l, hipStream_t onStream);
+
+// The "other" parameter gradients of a layer - adaptive adjacency, residual nn.Linear weights and biases - on the
+// stream of `bx` (inputs: Hprev / ZH / HA / Z2HA as bwd_layer_weights prepared them, DAx from bwd_x_columns).
+int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const float* Xall) {
   PASS_LOCALS(pass);
   LAYER_LOCALS(L);
-  // ---- from here on: the layer's weight gradients, on the second stream ----
-  if (twoStreams) {
-    HIP_OK(hipEventRecord(g_wf.step[0][l], s));
-    HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
+  hipStream_t xs = bx.c.s;
+  float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
+  float* Z2HA = tr + R.oZ2HA[par];
+  if (adp) {
+    RETURN_IF(adaptive_grad(bx, DAg, Hprev, rowsTB, H, dT));
+    RETURN_IF(adaptive_grad(bx, DAu, ZH, rowsTB, H, dT));
+    if (narrow) RETURN_IF(adaptive_grad(bx, DAx, Xall, rowsTB, C, dT, true));
+    else if (l == 0) RETURN_IF(adaptive_grad(bx, DAx, Xall, rowsTB, C, dT));
+    else RETURN_IF(adaptive_grad(bx, DAx, Xall + (size_t)(T - 1) * slab, B, C, dT));   // the other steps ride below
   }
+  // residual nn.Linear gradients (MultiATGCN.py:139-150)
+  const matgcn_linear_grads& gg = g->res_gate[l];
+  const matgcn_linear_grads& gu = g->res_update[l];
+  if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
+  RETURN_IF(zero_async(gg.weight, 128L * I, xs));
+  RETURN_IF(zero_async(gu.weight, 64L * I, xs));
+  const long rows = (long)rowsTB * Np;
+  RETURN_IF(linear_weight_grad(bx, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+  RETURN_IF(linear_weight_grad(bx, DPG2, 128, HA, H, rows, I, C, gg.weight));
+  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
+  RETURN_IF(zero_async(gg.bias, 128, xs));
+  RETURN_IF(zero_async(gu.bias, 64, xs));
+  hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
+  CHECK_LAUNCH();
+  return MATGCN_OK;
+}
+
+// Weight gradients of a graph layer, on the second stream when there is one (forked by the caller right after the
+// layer's chain: event step[0][l]; the x columns of the layer run on the main stream meanwhile and signal mixed[0][l]).
+// tailOnMain (the LAST layer processed, nothing left for the main stream to overlap with): the second stream keeps the
+// node-adaptive weight gradients and the pools, the other gradients (bwd_layer_other_grads) go to the main stream.
+int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  if (twoStreams) HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
   const float* Xall;
   if (l == 0) {
     float* X0tm = tr + R.oX0tm;
@@ -553,6 +620,11 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
   hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oR[l], Hprev, tr + R.oHC[l],
                      tr + R.oZ2[l], HA, Z2HA, seqN);
   CHECK_LAUNCH();
+  if (twoStreams && tailOnMain) {   // the main stream takes the other gradients once these operands exist
+    HIP_OK(hipEventRecord(g_wf.xdone[0][l], ws));
+    HIP_OK(hipStreamWaitEvent(s, g_wf.xdone[0][l], 0));
+    RETURN_IF(bwd_layer_other_grads(pass, L, b, Xall));
+  }
   // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
   float* dWpG = tr + R.oDWp[l][0];
   float* dWpU = tr + R.oDWp[l][1];
@@ -596,38 +668,17 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L) {
       t0 += nt;
     }
   }
-  if (adp) {
-    if (narrow) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT, true));
-    else if (l == 0) RETURN_IF(adaptive_grad(bw, DAx, Xall, rowsTB, C, dT));
-    else RETURN_IF(adaptive_grad(bw, DAx, Xall + (size_t)(T - 1) * slab, B, C, dT));   // the other steps ride below
-    RETURN_IF(adaptive_grad(bw, DAg, Hprev, rowsTB, H, dT));
-    RETURN_IF(adaptive_grad(bw, DAu, ZH, rowsTB, H, dT));
-  }
   hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
                      Np, 128, tr + R.oDBias[l][0]);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
                      64, tr + R.oDBias[l][1]);
   CHECK_LAUNCH();
-  // residual nn.Linear gradients (MultiATGCN.py:139-150)
-  {
-    const matgcn_linear_grads& gg = g->res_gate[l];
-    const matgcn_linear_grads& gu = g->res_update[l];
-    if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
-    RETURN_IF(zero_async(gg.weight, 128L * I, ws));
-    RETURN_IF(zero_async(gu.weight, 64L * I, ws));
-    const long rows = (long)rowsTB * Np;
-    RETURN_IF(linear_weight_grad(bw, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
-    RETURN_IF(linear_weight_grad(bw, DPG2, 128, HA, H, rows, I, C, gg.weight));
-    RETURN_IF(linear_weight_grad(bw, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
-    RETURN_IF(linear_weight_grad(bw, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
-    RETURN_IF(zero_async(gg.bias, 128, ws));
-    RETURN_IF(zero_async(gu.bias, 64, ws));
-    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
-    CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, ws, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
-    CHECK_LAUNCH();
+  if (!(twoStreams && tailOnMain)) {
+    if (twoStreams) HIP_OK(hipStreamWaitEvent(ws, g_wf.mixed[0][l], 0));   // DAx comes from the x columns (main stream)
+    RETURN_IF(bwd_layer_other_grads(pass, L, bw, Xall));
   }
+  RETURN_IF(bwd_pools_layer(pass, l, ws));   // node-adaptive weight gradients of this layer -> pools, node_emb, weights_g
   if (twoStreams) HIP_OK(hipEventRecord(g_wf.step[1][l], ws));
   return MATGCN_OK;
 }
@@ -661,12 +712,16 @@ int bwd_fuse_heads(Pass& pass) {
   return MATGCN_OK;
 }
 
-int bwd_pools(Pass& pass) {
+// parameter-only part of one layer: node-adaptive weight gradients -> pools, node_emb, weights_g (MultiATGCN.py:102-105).
+// Runs on the stream of the layer's weight gradients, right behind them: the pool GEMMs of the upper layers then hide
+// under the chain of the layer below instead of queueing up behind the last chain (40 small dependent launches).
+int bwd_pools_layer(Pass& pass, int l, hipStream_t onStream) {
   PASS_LOCALS(pass);
-  // ---- parameter-only part: node-adaptive weights -> pools, node_emb, weights_g (MultiATGCN.py:102-105) ----
-  float* EK = tr + R.oEK; float* FK = tr + R.oFK; float* TmpK = tr + R.oTmpK; float* dgain = tr + R.oDGain;
+  float* EK = tr + R.oEK; float* FK = tr + R.oFK; float* TmpK = tr + R.oTmpK; float* dgain = tr + R.oDPoolGain;
   const int Kt = P.KtotOrig;
-  for (int l = 0; l < P.L && !P.gcnOff; ++l)
+  if (P.gcnOff) return MATGCN_OK;
+  {
+    hipStream_t s = onStream;   // shadows the pass's stream: every launch below goes behind the layer's weight gradients
     for (int part = 0; part < 2; ++part) {
       const matgcn_agcn_params& ap = part == 0 ? prm->gate[l] : prm->update[l];
       const matgcn_agcn_grads& ag = part == 0 ? g->gate[l] : g->update[l];
@@ -713,7 +768,7 @@ int bwd_pools(Pass& pass) {
         }
       }
     }
-
+  }
   return MATGCN_OK;
 }
 
@@ -798,7 +853,6 @@ int backward_impl(Bwd& b, const float* dOut) {
   q.bw.c.s = q.ws;
 
   RETURN_IF(bwd_clear(q));
-  RETURN_IF(bwd_plain_operands(q));
   RETURN_IF(bwd_head(q, dOut));
   int cur = 0;   // which of the two sequence-gradient buffers holds the gradient of the current layer's output
   for (int l = P.L - 1; l >= 0; --l) {
@@ -822,15 +876,16 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(bwd_dense_layer(q, L));
     } else {
       RETURN_IF(bwd_chain(q, L));
+      if (q.twoStreams) HIP_OK(hipEventRecord(g_wf.step[0][l], q.s));    // the weight-gradient stream forks here
       RETURN_IF(bwd_x_columns(q, L));
-      RETURN_IF(bwd_layer_weights(q, L));
+      if (q.twoStreams) HIP_OK(hipEventRecord(g_wf.mixed[0][l], q.s));   // DAx is complete
+      RETURN_IF(bwd_layer_weights(q, L, l == 0));
     }
     if (l > 0) cur ^= 1;
   }
   if (q.twoStreams)
     for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l], 0));   // join
   RETURN_IF(bwd_fuse_heads(q));
-  RETURN_IF(bwd_pools(q));
   return bwd_adaptive_adjacency(q);
 }
 
@@ -870,10 +925,22 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
                        (int)rows, P.N, P.Np, H);
     CHECK_LAUNCH();
   }
+  // parameter-only operands of the backward (plain support stack, plain folded weights): on a side stream beside the
+  // forward (joined into the caller's stream before this call returns its last kernel)
+  RETURN_IF(wavefront_ready());
+  const bool side = g_wavefront_mode != 0;
+  hipStream_t aux = side ? g_wf.aux : c.s;
+  if (side) {
+    HIP_OK(hipEventRecord(g_wf.auxFork, c.s));
+    HIP_OK(hipStreamWaitEvent(aux, g_wf.auxFork, 0));
+  }
+  RETURN_IF(plain_operands(c, c.train, aux));
+  if (side) HIP_OK(hipEventRecord(g_wf.auxDone, aux));
   float* x0p = c.ws + P.oX0p;
   if (src) RETURN_IF(fuse_padded(c, src->series, x0p, src->label_start, src->rel_steps));
   else RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
+  if (side) HIP_OK(hipStreamWaitEvent(c.s, g_wf.auxDone, 0));
   const float* seqTop = c.ws + P.oSeq[P.L - 1];
   if (drop_mask) {   // mask (B, headT, N, H) on the steps the head convolves (fnn_off: the last one)
     const size_t ofs = (size_t)(P.T - P.headT) * P.B * P.Np * H;

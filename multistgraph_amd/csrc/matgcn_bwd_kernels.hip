@@ -166,6 +166,108 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
       }
 }
 
+// ---- the same GEMM, fast path for operands that are unit-stride along M (A) and along N (B) --------------------------
+// Conditions (checked by the launcher, tn_eligible): sAm == 1, sBn == 1, M and N multiples of 64, every other stride and
+// both base pointers multiples of 4 floats.  That is the graph-mix kernel's operand layout - a K-tile of A is 16 rows
+// of 256 contiguous bytes - so it gets the graph-mix kernel's pipeline instead of the generic one: K-tiles wait in
+// registers TWO tiles ahead of the MFMAs (the generic kernel runs one ahead: 16 MFMAs per wave cannot cover a memory
+// round trip), one float4 per thread and operand, 16-byte LDS stores into rows rotated by 16 * (k & 3) floats
+// (conflict-free fragment reads), loads unconditional (row index clamped, rows past the end of K zeroed by a select).
+// Call sites: the node-adaptive weight gradients (K = T*B rows per node and slot) and the residual nn.Linear
+// gradients (K = every (t, b, n) row, split over workgroups with atomics) - 6.8 of the backward's 28.7 ms of kernels.
+template <int ROLE>
+__global__ __launch_bounds__(256) void k_bgemm_tn(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][16 * 64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int wr = w >> 1, wc = w & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  int z = blockIdx.z;
+  const int part = z % g.split;
+  z /= g.split;
+  const int b2 = z % g.nb2, b1 = z / g.nb2;
+  const int kk = tid >> 4, sg = tid & 15;
+  const float* A = g.A + (size_t)b1 * g.bA1 + (size_t)b2 * g.bA2 + m0 + sg * 4;
+  const float* B = g.B + (size_t)b1 * g.bB1 + (size_t)b2 * g.bB2 + n0 + sg * 4;
+  float* C = g.C + (size_t)b1 * g.bC1 + (size_t)b2 * g.bC2;
+  const int kTiles = (g.K + 15) >> 4;
+  const int total = g.K2 * kTiles;
+  const int per = (total + g.split - 1) / g.split;
+  const int tBeg = part * per, tEnd = tBeg + per < total ? tBeg + per : total;
+  const int stPos = kk * 64 + (((sg + 4 * (kk & 3)) & 15) << 2);
+  // the fetch stream walks the (k2, k-tile) pairs of this part in order; past the end it re-reads the last tile, zeroed
+  int fk2 = tBeg / kTiles, fkt = tBeg - fk2 * kTiles, fetched = tBeg;
+  const int lastK2 = (tEnd - 1) / kTiles, lastKt = (tEnd - 1) - lastK2 * kTiles;
+  auto fetch = [&](float4& ra, float4& rb) {
+    const bool live = fetched < tEnd;
+    const int k2 = live ? fk2 : lastK2, kt = live ? fkt : lastKt;
+    ++fetched;
+    if (++fkt == kTiles) { fkt = 0; ++fk2; }
+    const int k = kt * 16 + kk, kc = min(k, g.K - 1);
+    const float4 va = *reinterpret_cast<const float4*>(A + (size_t)k2 * g.sAk2 + (size_t)kc * g.sAk);
+    const float4 vb = *reinterpret_cast<const float4*>(B + (size_t)k2 * g.sBk2 + (size_t)kc * g.sBk);
+    const bool ok = live && k < g.K;
+    ra = make_float4(ok ? va.x : 0.f, ok ? va.y : 0.f, ok ? va.z : 0.f, ok ? va.w : 0.f);
+    rb = make_float4(ok ? vb.x : 0.f, ok ? vb.y : 0.f, ok ? vb.z : 0.f, ok ? vb.w : 0.f);
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tBeg < tEnd) {
+    float4 ra0, rb0, ra1, rb1;
+    fetch(ra0, rb0);
+    *reinterpret_cast<float4*>(&As[0][stPos]) = ra0;
+    *reinterpret_cast<float4*>(&Bs[0][stPos]) = rb0;
+    fetch(ra0, rb0);
+    fetch(ra1, rb1);
+    __syncthreads();
+    const int rotA0 = (wr * 32 + j + 16 * kq) & 63, rotA1 = (wr * 32 + 16 + j + 16 * kq) & 63;
+    const int rotB0 = (wc * 32 + j + 16 * kq) & 63, rotB1 = (wc * 32 + 16 + j + 16 * kq) & 63;
+    auto mma = [&](int cur) {
+      const float* At = &As[cur][kq * 64];
+      const float* Bt = &Bs[cur][kq * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a0 = At[s * 256 + rotA0], a1 = At[s * 256 + rotA1];
+        const float b0 = Bt[s * 256 + rotB0], b1 = Bt[s * 256 + rotB1];
+        acc[0][0] = MFMA16(a0, b0, acc[0][0]);
+        acc[0][1] = MFMA16(a0, b1, acc[0][1]);
+        acc[1][0] = MFMA16(a1, b0, acc[1][0]);
+        acc[1][1] = MFMA16(a1, b1, acc[1][1]);
+      }
+    };
+    const int nT = tEnd - tBeg;
+    for (int it = 0; it < nT; it += 2) {
+      mma(0);
+      *reinterpret_cast<float4*>(&As[1][stPos]) = ra0;
+      *reinterpret_cast<float4*>(&Bs[1][stPos]) = rb0;
+      fetch(ra0, rb0);
+      __syncthreads();
+      if (it + 1 < nT) {
+        mma(1);
+        *reinterpret_cast<float4*>(&As[0][stPos]) = ra1;
+        *reinterpret_cast<float4*>(&Bs[0][stPos]) = rb1;
+        fetch(ra1, rb1);
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wr * 32 + p * 16 + 4 * kq + e, n = n0 + wc * 32 + q * 16 + j;
+        float* dst = C + (size_t)m * g.sCm + (size_t)n * g.sCn;
+        const float v = g.alpha * acc[p][q][e];
+        if (g.mode == 1) unsafeAtomicAdd(dst, v);
+        else *dst = (g.beta != 0.f) ? v + g.beta * *dst : v;
+      }
+}
+
 // ---- plain (row-major) folded node-adaptive weights for the backward GEMMs ------------------------------------
 // Wp[n][s][i][o] = the weights the forward node kernels contract with, slot s = 0 (identity, with the diagonal
 // supports folded in) or a dense slot: g_k * sum_d E[n][d] Wpool[d][k][i][o]  (MultiATGCN.py:102-105; StackMap)
@@ -327,6 +429,8 @@ struct ChainArgs {
   float* dh;             // running dh_{t-1}: written by part 3, extended by part 4; the next step's fused kernel adds
                          // slot 0 of the gate AGCN's dA and its transposed mix to form the carry
   float* dr;             // scratch [B][Np][64]
+  int mixParts;          // the transposed mixes arrive as this many partial results (split by support slot) ...
+  long mixPartStride;    // ... this many floats apart: whoever reads dzhMix / dhMix / carryMix adds them up
   int B, N, Np, S;
   int dense;             // gcn_off: the layer IS a dense GRU cell on (x, h): "ha" is h_{t-1}, no blend (blend == null)
 };
@@ -409,8 +513,10 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
         const float4 c0 = ld4(a.dcarry, idx), c1 = ld4(f.carryA, ((b * a.S) * a.Np + n) * 64 + c4);
         dhp = make_float4(dhp.x + c0.x + c1.x, dhp.y + c0.y + c1.y, dhp.z + c0.z + c1.z, dhp.w + c0.w + c1.w);
         if (f.carryMix) {
-          const float4 c2 = ld4(f.carryMix, idx);
-          dhp = make_float4(dhp.x + c2.x, dhp.y + c2.y, dhp.z + c2.z, dhp.w + c2.w);
+          for (int pt = 0; pt < a.mixParts; ++pt) {
+            const float4 c2 = ld4(f.carryMix + (size_t)pt * a.mixPartStride, idx);
+            dhp = make_float4(dhp.x + c2.x, dhp.y + c2.y, dhp.z + c2.z, dhp.w + c2.w);
+          }
         }
       }
       const float4 hp = a.hprev ? ld4(a.hprev, idx) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -552,7 +658,8 @@ __global__ __launch_bounds__(256) void k_chain_cell_gate(ChainArgs a) {
   const int o = idx & 63;
   const size_t b = row / a.Np, n = row - b * a.Np;
   float dzh = a.dzhA[((b * a.S) * a.Np + n) * 64 + o];
-  if (a.dzhMix) dzh += a.dzhMix[idx];
+  if (a.dzhMix)
+    for (int pt = 0; pt < a.mixParts; ++pt) dzh += a.dzhMix[idx + (size_t)pt * a.mixPartStride];
   const float h = a.hprev ? a.hprev[idx] : 0.f, z = a.z[idx], r = a.r[idx];
   a.dh[idx] += dzh * z;
   a.dpg[row * 128 + o] = dzh * h * z * (1.f - z);
@@ -562,8 +669,8 @@ __global__ __launch_bounds__(256) void k_chain_cell_gate(ChainArgs a) {
 // gradient of a layer's initial state, unpadded (B, N, 64): dh + slot 0 of the gate AGCN's dA of step 0 + its transposed
 // mix - exactly what the fused chain kernel adds up as the carry into an earlier step (dA / mix null: dense GRU layer)
 __global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, const float* __restrict__ dA,
-                                                 const float* __restrict__ mix, float* __restrict__ out, int B, int N,
-                                                 int Np, int S) {
+                                                 const float* __restrict__ mix, int mixParts, long mixPartStride,
+                                                 float* __restrict__ out, int B, int N, int Np, int S) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)B * N * 64) return;
   const int o = idx & 63;
@@ -571,7 +678,8 @@ __global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, c
   const size_t p = (b * Np + n) * 64 + o;
   float v = dh[p];
   if (dA) v += dA[((b * S) * Np + n) * 64 + o];
-  if (mix) v += mix[p];
+  if (mix)
+    for (int pt = 0; pt < mixParts; ++pt) v += mix[p + (size_t)pt * mixPartStride];
   out[idx] = v;
 }
 

@@ -174,7 +174,7 @@ struct TrainPlan {
   long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
   long oX0tm, oHprev[2], oZH[2], oHA[2], oZ2HA[2], oDX0;
   long oMixN;                              // [Np][T*B*C0] transposed mix of the narrow layer-0 x columns
-  long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDOutRows;
+  long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDPoolGain, oDOutRows;
   long oStP;                               // [Ks*Np][NpC] plain support stack (A operand of the transposed mix)
   long floats;
 };
@@ -214,14 +214,15 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
     R->oHprev[q] = take(seq); R->oZH[q] = take(seq); R->oHA[q] = take(seq); R->oZ2HA[q] = take(seq);
   }
   R->oDSeq[0] = take(seq); R->oDSeq[1] = take(seq);
-  R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab); R->oMixOut = take(slab);
+  R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab);
+  R->oMixOut = take(slab * (P.Ks > 1 ? P.Ks : 1));   // one partial result per dense slot (split transposed mix)
   R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
   R->oMixN = take((long)P.T * P.B * P.Np * P.C0);
   R->oDT = take((long)P.per * P.N * P.N); R->oDL = take((long)P.N * P.N);   // dT: one (N,N) per Chebyshev order
   const long nEnt = P.KtotOrig + 4;   // stack entries the pool gradients walk (cheb_order = 1: up to 2 + 3 on one pool index)
   R->oEK = take(nEnt * P.N * P.d); R->oFK = take(nEnt * P.N);
-  R->oTmpK = take(nEnt * P.N * P.d); R->oDGain = take(64);
+  R->oTmpK = take(nEnt * P.N * P.d); R->oDGain = take(64); R->oDPoolGain = take(64);
   R->oDOutRows = take((long)P.B * P.Np * P.CH);
   R->oStP = take((long)P.Ks * P.Np * P.NpC);
   R->floats = o;
@@ -289,6 +290,8 @@ struct Wavefront {
   hipStream_t chain[MATGCN_MAX_LAYERS];            // [0] unused: layer 0 runs on the caller's stream
   hipStream_t xpart[MATGCN_MAX_LAYERS];
   hipEvent_t fork, done[MATGCN_MAX_LAYERS];
+  hipStream_t aux;                                 // parameter-only side work of forward_train (plain copies for the backward)
+  hipEvent_t auxFork, auxDone;
   hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
   hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
@@ -319,6 +322,9 @@ int wavefront_ready() {
     HIP_OK(hipStreamCreateWithFlags(&g_wf.xpart[l], hipStreamNonBlocking));
   }
   HIP_OK(hipEventCreateWithFlags(&g_wf.fork, hipEventDisableTiming));
+  HIP_OK(hipStreamCreateWithFlags(&g_wf.aux, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.auxFork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.auxDone, hipEventDisableTiming));
   for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
     HIP_OK(hipEventCreateWithFlags(&g_wf.done[l], hipEventDisableTiming));
     for (int t = 0; t < MAX_STEPS; ++t) {

@@ -77,6 +77,10 @@ struct MixArgs {
   long sN, sK, sT;
   long outFloats;        // extent of `out` (bounds the write-through buffer descriptor; 0: plain stores)
   int Np, N, Ks, nK, nColTiles, nRowTiles;
+  // split reduction (blockIdx.y = part): part p multiplies reduction rows [p*nK*16, ..) of St with the matching rows
+  // of X and writes its own partial result - the transposed mix of the backward splits by support slot
+  int parts = 1;
+  long aPartStride = 0, xPartStride = 0, outPartStride = 0;
 };
 
 struct HeadArgs {

@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1, j = lane & 15, kq = lane >> 4;
   const int kk = tid >> 4, sg = tid & 15;
-  const float* ap = a.St + (size_t)kk * a.ldS + row0 + sg * 4;
-  const float* bp = a.X + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
+  const int part = blockIdx.y;     // split reduction (MixArgs.parts): 0 unless the launch has a second grid dimension
+  const float* ap = a.St + (size_t)part * a.aPartStride + (size_t)kk * a.ldS + row0 + sg * 4;
+  const float* bp = a.X + (size_t)part * a.xPartStride + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
   // LDS image of a K-tile: row kk (one reduction index, 64 values) rotated by 16*(kk&3) floats, so that the four
   // k rows one 16x16x4 MFMA step reads (kq = 0..3) sit in four different bank quarters
   const int stPos = kk * 64 + (((sg + 4 * (kk & 3)) & 15) << 2);
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
         stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
       }
   const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+  float* outp = a.out + (size_t)part * a.outPartStride;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int lrow = u * 8 + (lane >> 3), q = lane & 7;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
         const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
         __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
       } else {
-        *reinterpret_cast<float4*>(a.out + off) = v;
+        *reinterpret_cast<float4*>(outp + off) = v;
       }
     }
   }

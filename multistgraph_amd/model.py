@@ -357,8 +357,8 @@ class MultiATGCN(AbstractTrafficStateModel):
     def gradient_bucket(self) -> Optional[torch.Tensor]:
         """The flat fp32 buffer that holds the gradient of every HIP-path parameter after ``loss.backward()`` (their
         ``.grad`` are views of it), for ONE all-reduce in data-parallel training (sharding.bucket_allreduce_mean_);
-        None when some gradient lives elsewhere (accumulated gradients, a second batch size) - then exchange the
-        ``.grad`` tensors themselves.  The host-side static_initial_* layers are not part of it."""
+        None when some gradient lives elsewhere (gradients accumulated over several backward calls) - then exchange
+        the ``.grad`` tensors themselves.  The host-side static_initial_* layers are not part of it."""
         for hp in self._paths.values():
             b = hp.grad_bucket
             if b is None:

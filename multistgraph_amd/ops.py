@@ -248,8 +248,7 @@ class HotPath:
         self._prepared_ok = False
         self._train = None
         self.train_generation = 0
-        self.grad_bucket: Optional[torch.Tensor] = None   # flat buffer the gradients of backward() are views of
-        self._grad_key = None
+        self.grad_bucket: Optional[torch.Tensor] = None   # flat buffer the gradients of the LAST backward() are views of
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _stream(self):
@@ -405,23 +404,16 @@ class HotPath:
     def _grad_views(self, state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Every gradient matgcn_backward returns is a view of ONE flat fp32 buffer (``grad_bucket``, 15.5 MB at
         N = 403), so that the gradient exchange of data-parallel training is a single all-reduce of that buffer with no
-        concatenation or copy-back (torch autograd adopts the views as ``p.grad``).  The buffer is reused from step to
-        step - unless a parameter's ``.grad`` still lives in it (gradient accumulation, zero_grad(set_to_none=False)):
-        overwriting it would corrupt the sum autograd is about to form, so that call gets a buffer of its own."""
+        concatenation or copy-back (torch autograd adopts the views as ``p.grad``).  Every call gets a buffer of its
+        own from torch's caching allocator - gradients handed out earlier stay valid for as long as somebody holds
+        them (gradient accumulation, zero_grad(set_to_none=False), callers that compare two backward results), and
+        once they are dropped the allocator hands the same block back, so a training loop reuses one block anyway."""
         names = [k for k in state if not k.startswith("static_initial")]
-        key = tuple((k, tuple(state[k].shape)) for k in names)
         offs, total = {}, 0
         for k in names:
             offs[k] = total
             total += (state[k].numel() + 63) // 64 * 64        # every view starts on a 256-byte boundary
-        bucket = self.grad_bucket if self._grad_key == key else None
-        if bucket is not None:
-            lo, hi = bucket.data_ptr(), bucket.data_ptr() + bucket.numel() * 4
-            if any(getattr(state[k], "grad", None) is not None and lo <= state[k].grad.data_ptr() < hi for k in names):
-                bucket = torch.zeros(total, dtype=torch.float32, device=self.device)    # one-off, not kept
-        else:
-            bucket = self.grad_bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
-            self._grad_key = key
+        bucket = self.grad_bucket = torch.zeros(total, dtype=torch.float32, device=self.device)
         return {k: bucket[offs[k]:offs[k] + state[k].numel()].view(state[k].shape) for k in names}
 
     def backward(self, x, d_out: torch.Tensor, state: Dict[str, torch.Tensor],
