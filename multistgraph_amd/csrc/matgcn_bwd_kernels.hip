@@ -30,6 +30,12 @@ struct GemmArgs {
 };
 
 #define BG_LD 80   // LDS row pitch (floats): lanes with kq = 0..3 land 16 banks apart
+// column swizzle of the staged tiles: element (k, x) lives in column x ^ (16 * ((k >> 2) & 3)).  A thread that loaded
+// four CONSECUTIVE k of one row (K-contiguous operands: pre-activation gradients, plain weights) writes rows k, k+1, ..
+// and the four threads that share a row write rows 4 apart - 64 floats apart at this pitch, i.e. the SAME bank; the
+// swizzle spreads them over the four 16-bank groups, and the fragment reads (k = 4 s + kq: the term is 16 * (s & 3),
+// wave-uniform) stay conflict-free.  Round 1 measured half of this kernel's LDS-active cycles as bank conflicts.
+#define BG_SWZ(k) ((((k) >> 2) & 3) << 4)
 #ifndef BG_KH
 #define BG_KH 1    // 16-wide K halves per staged tile (2 was measured: no gain at the backward's shapes, twice the LDS)
 #endif
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
     for (int h = 0; h < BG_KH; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        As[buf][16 * h + ak[i]][am[i]] = ra[h][i];
-        Bs[buf][16 * h + bk[i]][bn[i]] = rb[h][i];
+        As[buf][16 * h + ak[i]][am[i] ^ BG_SWZ(ak[i])] = ra[h][i];
+        Bs[buf][16 * h + bk[i]][bn[i] ^ BG_SWZ(bk[i])] = rb[h][i];
       }
   };
   if (tBeg < tEnd) {
@@ -138,9 +144,9 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
         const int k = 4 * s + kq;
         float av[2], bv[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = As[buf][k][wm * 32 + a * 16 + j];
+        for (int a = 0; a < 2; ++a) av[a] = As[buf][k][(wm * 32 + a * 16 + j) ^ ((s & 3) << 4)];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bv[b] = Bs[buf][k][wn * 32 + b * 16 + j];
+        for (int b = 0; b < 2; ++b) bv[b] = Bs[buf][k][(wn * 32 + b * 16 + j) ^ ((s & 3) << 4)];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
