@@ -468,7 +468,7 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
       f.carryA = (t == T - 1) ? nullptr : DAg + (at + slab) * S;
       f.carryMix = (t == T - 1 || P.Ks <= 0) ? nullptr : MixOut;
       f.ruh = RU + C; f.rgh = RG + C; f.ldW = I;
-      hipLaunchKernelGGL(k_chain_res_fused, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
+      hipLaunchKernelGGL(k_chain_res_fused<64>, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
       CHECK_LAUNCH();
     }
     RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
@@ -842,7 +842,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
     if (!optedIn[dev]) {
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused),
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_res_fused<64>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, q.fusedLds));
       optedIn[dev] = true;
     }

@@ -493,22 +493,29 @@ struct FusedResArgs {
 __device__ __forceinline__ float4 ld4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
 __device__ __forceinline__ float get4(const float4& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : x == 2 ? v.z : v.w; }
 
+// ROWS rows per workgroup (64, or 32: twice the workgroups - the kernel streams ~120 MB per launch and 416 workgroups of
+// 64 rows are 1.6 per CU, too few to keep enough loads in flight).  The staged tile is k-major; row x of reduction
+// index k lives in column (x + 4 * (k >> 2)) & 63: the threads of phase 1 hold FOUR consecutive k of one row and the
+// 16 threads that share a row hold k-quads 16 rows apart - without the rotation all of them write into one bank.
+#define CF_ROT(k) (4 * ((k) >> 2))
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ps = lds;                    // [128 k][CF_LD] k-major A tile (element (k, local row)); the weights (B operands,
                                       // 48 KB shared by all workgroups) come straight from L2 so that several
                                       // workgroups fit a CU
   __shared__ float red[256];
+  constexpr int NP = ROWS / 32;       // 16-row sub-tiles per wave: wave (wm, wn) owns rows wm*(ROWS/2) + 16 p
   const ChainArgs& a = f.c;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
-  const size_t rows = (size_t)a.B * a.Np, row0 = (size_t)blockIdx.x * 64;
+  const size_t rows = (size_t)a.B * a.Np, row0 = (size_t)blockIdx.x * ROWS;
   const float g = sigmoid_f(a.blend[0]);
   // phase 1 (one thread per row and 4 columns, 16-byte accesses): everything that does not need a contraction -
   // dpu2 and the r half of dpg2 -> global + A tile; dha so far and ha*z2*(1-z2) -> row scratch; blend partial sum
   float part = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < ROWS / 16; ++it) {
     const int q = tid + 256 * it, lr = q >> 4, c4 = (q & 15) * 4;
     float dpu2[4] = {0.f, 0.f, 0.f, 0.f}, drr[4] = {0.f, 0.f, 0.f, 0.f};
     if (row0 + lr < rows) {
@@ -548,10 +555,11 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
       *reinterpret_cast<float4*>(a.dha + idx) = make_float4(dha0[0], dha0[1], dha0[2], dha0[3]);
       *reinterpret_cast<float4*>(const_cast<float*>(a.dzh2) + idx) = make_float4(c1v[0], c1v[1], c1v[2], c1v[3]);
     }
+    const int pos = (lr + CF_ROT(c4)) & 63;          // the four k of this thread share a k-quad: one rotation
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      Ps[(c4 + x) * CF_LD + lr] = dpu2[x];
-      Ps[(64 + c4 + x) * CF_LD + lr] = drr[x];
+      Ps[(c4 + x) * CF_LD + pos] = dpu2[x];
+      Ps[(64 + c4 + x) * CF_LD + pos] = drr[x];       // (64 + c4) >> 2 = 16 + (c4 >> 2): the same rotation mod 64
     }
   }
   red[tid] = part;
@@ -562,21 +570,21 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
   }
   if (tid == 0) unsafeAtomicAdd(a.dblend, red[0] * g * (1.f - g));
   // phase 2: d(z2*ha) = dpu2 . RU[:, C:]
-  f32x4 acc[2][2];
+  f32x4 acc[NP][2];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int s = 0; s < 16; ++s) {
-    const int k = 4 * s + kq;
-    float av[2], bv[2];
+    const int k = 4 * s + kq;                        // k >> 2 = s: the rotation is 4 s, wave-uniform
+    float av[NP], bv[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) av[p] = Ps[k * CF_LD + wm * 32 + p * 16 + j];
+    for (int p = 0; p < NP; ++p) av[p] = Ps[k * CF_LD + ((wm * (ROWS / 2) + p * 16 + j + 4 * s) & 63)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) bv[q] = f.ruh[(size_t)k * f.ldW + wn * 32 + q * 16 + j];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int q = 0; q < 2; ++q) acc[p][q] = MFMA16(av[p], bv[q], acc[p][q]);
   }
@@ -584,12 +592,12 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
   // phase 3: the z half of dpg2 -> global + A tile; dha so far moves into the accumulators of the second contraction
   // (the row scratch written in phase 1 is read back by other threads of this workgroup: ordered by the barriers)
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
-        const int lr = wm * 32 + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
+        const int lr = wm * (ROWS / 2) + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
         float dz = 0.f, dha = 0.f;
         if (row0 + lr < rows) {
           const size_t idx = (row0 + lr) * 64 + col;
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
           dz = dzh2 * a.dzh2[idx];
           a.dpg2[(row0 + lr) * 128 + col] = dz;
         }
-        Ps[col * CF_LD + lr] = dz;
+        Ps[col * CF_LD + ((lr + CF_ROT(col)) & 63)] = dz;
         acc[p][q][e4] = dha;
       }
   __syncthreads();
@@ -606,24 +614,24 @@ __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {
 #pragma unroll 8
   for (int s = 0; s < 32; ++s) {
     const int k = 4 * s + kq;
-    float av[2], bv[2];
+    float av[NP], bv[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) av[p] = Ps[k * CF_LD + wm * 32 + p * 16 + j];
+    for (int p = 0; p < NP; ++p) av[p] = Ps[k * CF_LD + ((wm * (ROWS / 2) + p * 16 + j + 4 * s) & 63)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) bv[q] = f.rgh[(size_t)k * f.ldW + wn * 32 + q * 16 + j];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int q = 0; q < 2; ++q) acc[p][q] = MFMA16(av[p], bv[q], acc[p][q]);
   }
   // phase 5: graph cell output algebra (MultiATGCN.py:127)
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
-        const int lr = wm * 32 + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
+        const int lr = wm * (ROWS / 2) + p * 16 + 4 * kq + e4, col = wn * 32 + q * 16 + j;
         if (row0 + lr >= rows) continue;
         const size_t idx = (row0 + lr) * 64 + col;
         const float dha = acc[p][q][e4];

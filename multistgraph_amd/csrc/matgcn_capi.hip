@@ -109,7 +109,9 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   auto take = [&](long n) { long at = o; o += rup(n, 64); return at; };
   P->oSt = take((long)P->Np * P->Mp);
   const long plainN = (D->cheb_k > 2) ? (long)P->Np * P->NpC : 0;
-  P->oPlainA = take(plainN); P->oPlainB = take(plainN); P->oPlainC = take(plainN);
+  // plainA also stages the adaptive adjacency (written row-wise, then transposed into its stack slot)
+  P->oPlainA = take((D->cheb_k > 2 || adp) ? (long)P->Np * P->NpC : 0);
+  P->oPlainB = take(plainN); P->oPlainC = take(plainN);
   for (int l = 0; l < P->L; ++l) {
     P->Cl[l] = (l == 0) ? P->C0 : H;
     P->Cpad[l] = (int)rup(P->Cl[l], 16);
@@ -887,11 +889,12 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   const int per = P.per;  // stack slots per first-order support
   if (P.Mp > 0) RETURN_IF(zero_async(St, (long)P.Np * P.Mp, c.s));
   const bool cheb = dims->cheb_k > 2 && P.nDenseFirst > 0;
-  float* plainA = cheb ? prep + P.oPlainA : nullptr;  // T_{k-1}
+  const bool hasAdp = dims->adp_mode != MATGCN_ADP_NONE && !P.gcnOff;
+  float* plainA = (cheb || hasAdp) ? prep + P.oPlainA : nullptr;  // T_{k-1}; staging of the adaptive adjacency
   float* plainB = cheb ? prep + P.oPlainB : nullptr;  // T_{k-2} / product scratch
   float* plainC = cheb ? prep + P.oPlainC : nullptr;
+  if (cheb || hasAdp) RETURN_IF(zero_async(plainA, (long)P.Np * P.NpC, c.s));
   if (cheb) {
-    RETURN_IF(zero_async(plainA, (long)P.Np * P.NpC, c.s));
     RETURN_IF(zero_async(plainB, (long)P.Np * P.NpC, c.s));
     RETURN_IF(zero_async(plainC, (long)P.Np * P.NpC, c.s));
   }
@@ -904,14 +907,17 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
     const bool adaptive = (dims->adp_mode != MATGCN_ADP_NONE) && f == 0;   // always the first dense support
     if (adaptive) {
       const bool bi = dims->adp_mode == MATGCN_ADP_BI;
-      hipLaunchKernelGGL(k_adaptive_adj, dim3(P.N), dim3(256), 0, c.s, bi ? params->node_emb : params->node_vec1,
-                         bi ? nullptr : params->node_vec2, bi ? dims->embed_dim : dims->adj_rank, bi ? 1 : 0, P.N,
-                         St, P.Mp, col0, plainA, P.NpC);
+      hipLaunchKernelGGL(k_adaptive_adj, dim3(P.N), dim3(256), (size_t)P.N * sizeof(float), c.s,
+                         bi ? params->node_emb : params->node_vec1, bi ? nullptr : params->node_vec2,
+                         bi ? dims->embed_dim : dims->adj_rank, bi ? 1 : 0, P.N, plainA, P.NpC);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_static_transpose, tgrid, dim3(256), 0, c.s, plainA, P.N, P.NpC, St, P.Mp, col0, plainA, P.NpC,
+                         accumulate);
     } else {
       const int sidx = f - (dims->adp_mode != MATGCN_ADP_NONE ? 1 : 0);
       hipLaunchKernelGGL(k_static_transpose, tgrid, dim3(256), 0, c.s,
-                         params->static_supports + (size_t)sidx * P.N * P.N, P.N, St, P.Mp, col0, plainA, P.NpC,
-                         accumulate);
+                         params->static_supports + (size_t)sidx * P.N * P.N, P.N, P.N, St, P.Mp, col0,
+                         cheb ? plainA : nullptr, P.NpC, accumulate);
     }
     CHECK_LAUNCH();
     // Chebyshev orders 2..cheb_k-1 of this support: T_k = 2 S T_{k-1} - T_{k-2} (T_0 = I, T_1 = S).

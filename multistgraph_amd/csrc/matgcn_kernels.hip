@@ -37,26 +37,29 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // Adaptive adjacency, one workgroup per row n (MultiATGCN.py:80-83):
 //   A[n][m] = softmax_m(relu(sum_r E1[n][r] * E2[r][m]))      (unidirection)
 //   A[n][m] = softmax_m(relu(sum_d E[n][d]  * E[m][d]))       (bidirection)
-// written transposed into St[m][col0 + n]; optionally also plain into P[n][ldP] (Chebyshev input).
+// Every logit is computed ONCE (kept in LDS: `lds` holds N floats) and the row is written contiguously into the plain
+// matrix P[n][ldP]; k_static_transpose then moves it into its transposed stack slot with tiled, coalesced accesses
+// (round 1 recomputed the logits in all three softmax passes and scattered 4-byte stores down a column of St).
 __global__ __launch_bounds__(256) void k_adaptive_adj(const float* __restrict__ e1, const float* __restrict__ e2,
-                                                      int rank, int bidir, int N, float* __restrict__ St, int ldS,
-                                                      int col0, float* __restrict__ plain, int ldP) {
+                                                      int rank, int bidir, int N, float* __restrict__ plain, int ldP) {
+  extern __shared__ float logits[];      // N floats
   __shared__ float red[256];
   __shared__ float erow[64];
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int r = tid; r < rank; r += 256) erow[r] = e1[(size_t)n * rank + r];
   __syncthreads();
-  auto logit = [&](int m) {
+  float mx = 0.f;  // relu output is >= 0
+  for (int m = tid; m < N; m += 256) {
     float s = 0.f;
     if (bidir) {
       for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e1[(size_t)m * rank + r], s);
     } else {
       for (int r = 0; r < rank; ++r) s = fmaf(erow[r], e2[(size_t)r * N + m], s);
     }
-    return fmaxf(s, 0.f);
-  };
-  float mx = 0.f;  // relu output is >= 0
-  for (int m = tid; m < N; m += 256) mx = fmaxf(mx, logit(m));
+    s = fmaxf(s, 0.f);
+    logits[m] = s;
+    mx = fmaxf(mx, s);
+  }
   red[tid] = mx;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -66,7 +69,11 @@ __global__ __launch_bounds__(256) void k_adaptive_adj(const float* __restrict__ 
   mx = red[0];
   __syncthreads();
   float sum = 0.f;
-  for (int m = tid; m < N; m += 256) sum += expf(logit(m) - mx);
+  for (int m = tid; m < N; m += 256) {
+    const float e = expf(logits[m] - mx);
+    logits[m] = e;
+    sum += e;
+  }
   red[tid] = sum;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -74,26 +81,23 @@ __global__ __launch_bounds__(256) void k_adaptive_adj(const float* __restrict__ 
     __syncthreads();
   }
   const float inv = 1.0f / red[0];
-  for (int m = tid; m < N; m += 256) {
-    const float p = expf(logit(m) - mx) * inv;
-    St[(size_t)m * ldS + col0 + n] = p;
-    if (plain) plain[(size_t)n * ldP + m] = p;
-  }
+  for (int m = tid; m < N; m += 256) plain[(size_t)n * ldP + m] = logits[m] * inv;
 }
 
 // static first-order supports (model.supports[s][1], MultiATGCN.py:269-283) -> transposed slots
 // (accumulate: add into the slot instead - cheb_order = 1 sums its dense supports, see StackMap)
-__global__ __launch_bounds__(256) void k_static_transpose(const float* __restrict__ S, int N, float* __restrict__ St,
-                                                          int ldS, int col0, float* __restrict__ plain, int ldP,
-                                                          int accumulate) {
+// (ldSrc: leading dimension of S - N for the reference's supports, the plain buffer's pitch for the adaptive adjacency)
+__global__ __launch_bounds__(256) void k_static_transpose(const float* __restrict__ S, int N, int ldSrc,
+                                                          float* __restrict__ St, int ldS, int col0,
+                                                          float* __restrict__ plain, int ldP, int accumulate) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: m block, by: n block
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     const int n = by + j, m = bx + tx;
-    const float v = (n < N && m < N) ? S[(size_t)n * N + m] : 0.f;
+    const float v = (n < N && m < N) ? S[(size_t)n * ldSrc + m] : 0.f;
     tile[j][tx] = v;
-    if (plain && n < N && m < N) plain[(size_t)n * ldP + m] = v;
+    if (plain && plain != S && n < N && m < N) plain[(size_t)n * ldP + m] = v;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
