@@ -233,6 +233,22 @@ def test_ragged_batches_vs_oracle(batch, lib_built):
     assert max_norm_err(got, want) <= E2E_TOL
 
 
+def test_config2_dc237_batch64_vs_oracle(lib_built):
+    """BASELINE config 2 at its full batch: DC 237 nodes, in 24 h -> out 12 h, B = 64, fp32 - against the CPU oracle
+    (hoisted order; the golden case dc237_out12 pins the same configuration to the reference at B = 4)"""
+    from multistgraph_amd import synthetic as syn
+    from oracle import matgcn_oracle as O
+    c = Case("dc237_out12")
+    c.b = 64
+    c.x, c.y = syn.make_batch_arrays(64, c.n, c.out, 2024, feat=c.feat)
+    hp, dev = _path(c, lib_built)
+    got = hp.forward(torch.from_numpy(c.x).to(dev)).cpu().numpy()
+    want = O.forward(torch.from_numpy(c.x), O.to_tensors(c.state), O.supports_as_tensors(c.gold["static_supports"]),
+                     c.oracle_cfg(), faithful=False).numpy()
+    assert got.shape == (64, 12, 237, 1)
+    assert max_norm_err(got, want) <= E2E_TOL
+
+
 def test_linearity_of_graph_mix(lib_built):
     # size-independent property at the Baltimore shape: the gate pre-activation is affine in (x, h):
     # f(a) + f(b) - f(0) == f(a + b)
@@ -247,16 +263,21 @@ def test_linearity_of_graph_mix(lib_built):
     assert max_norm_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= 1e-5
 
 
-def test_wavefront_and_serial_schedules_agree_bitwise(lib_built):
+@pytest.mark.parametrize("name", ["dc237_out12", "tiny_multi_uni_c2_static", "tiny_identity_non_c1", "tiny_multi_uni_dyn7"])
+def test_wavefront_and_serial_schedules_agree_bitwise(name, lib_built):
     # the layer wavefront only reorders independent launches: results must be identical to the serial schedule
-    c = Case("dc237_out12")
+    c = Case(name)
     hp, dev = _path(c, lib_built)
     x = torch.from_numpy(c.x).to(dev)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
     prev = hp.lib.matgcn_set_wavefront(1)
-    a = hp.forward(x).cpu().numpy()
-    hp.lib.matgcn_set_wavefront(0)
-    b = hp.forward(x).cpu().numpy()
-    hp.lib.matgcn_set_wavefront(prev)
+    try:
+        a = hp.forward(x, h0).cpu().numpy()
+        hp.lib.matgcn_set_wavefront(0)
+        b = hp.forward(x, h0).cpu().numpy()
+    finally:
+        hp.lib.matgcn_set_wavefront(prev)
     assert np.array_equal(a, b)
 
 
