@@ -142,6 +142,20 @@ int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp
   return gemm(g, P.N, b.c.s, rows > P.B ? BG_X_NODE : BG_CHAIN_NODE);
 }
 
+// the same contraction on the dedicated node kernel (64 hidden / input columns per slot, whole 16-byte rows):
+// dA[rows][s][n][0:64] (+)= dPre[rows][n][0:O] . Wp[n][s][iOfs .. iOfs+63][0:O]^T
+int node_contract(const Bwd& b, const float* dPre, int O, const float* Wp, int I, int iOfs, int rows, float* dA, float beta) {
+  const Plan& P = b.c.P;
+  ChainNodeArgs cn;
+  memset(&cn, 0, sizeof(cn));
+  cn.dPre = dPre; cn.Wp = Wp; cn.dA = dA; cn.I = I; cn.iOfs = iOfs; cn.rows = rows; cn.N = P.N; cn.Np = P.Np; cn.S = b.c.R.S;
+  cn.beta = beta;
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)P.N);
+  if (O == 128) hipLaunchKernelGGL((k_chain_node<false, 128>), grid, dim3(512), 0, b.c.s, cn);
+  else hipLaunchKernelGGL((k_chain_node<false, 64>), grid, dim3(512), 0, b.c.s, cn);
+  return launch_ok();
+}
+
 // where the forward left the graph-mixed rows G[s'][n][(k2, k)][i] of a range of steps: strides in floats
 struct MixedRows {
   const float* G;
@@ -471,13 +485,21 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
       hipLaunchKernelGGL(k_chain_res_fused<64>, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
       CHECK_LAUNCH();
     }
-    RETURN_IF(node_gemm_transposed(b, DPU + at, 64, WpU, I, C, H, B, DAu + at * S, 0.f));
-    RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut, true, slab));
-    hipLaunchKernelGGL(k_chain_cell_gate, eg, dim3(256), 0, s, a);
+    // update block: dA_u = dpu . WpU^T (h columns), then its transposed mix
+    ChainNodeArgs cn;
+    memset(&cn, 0, sizeof(cn));
+    cn.c = a; cn.I = I; cn.iOfs = C; cn.rows = B; cn.N = N; cn.Np = Np; cn.S = S;
+    const dim3 ngrid((unsigned)((B + 63) / 64), (unsigned)N);
+    cn.dPre = DPU + at; cn.Wp = WpU; cn.dA = DAu + at * S; cn.beta = 0.f;
+    hipLaunchKernelGGL((k_chain_node<false, 64>), ngrid, dim3(512), 0, s, cn);
     CHECK_LAUNCH();
+    RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut, true, slab));
+    // gate block: the gate algebra (prologue) and dA_g = dpg . WpG^T in one kernel, then its transposed mix
     // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
     // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
-    RETURN_IF(node_gemm_transposed(b, DPG + 2 * at, 128, WpG, I, C, H, B, DAg + at * S, mergeAbove ? 1.f : 0.f));
+    cn.dPre = nullptr; cn.Wp = WpG; cn.dA = DAg + at * S; cn.beta = mergeAbove ? 1.f : 0.f;
+    hipLaunchKernelGGL((k_chain_node<true, 128>), ngrid, dim3(512), 0, s, cn);
+    CHECK_LAUNCH();
     RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut, true, slab));   // the carry itself is formed by the next step's kernel
   }
   if (b.dH0) {   // what step 0 would carry into a step before it: dh + slot 0 of the gate AGCN's dA + its transposed mix
@@ -510,8 +532,8 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
                        P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
     CHECK_LAUNCH();
   } else if (l == 0) {   // a 64-channel input layer: nothing below to ride with
-    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f));
-    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f));
+    RETURN_IF(node_contract(b, DPG, 128, WpG, I, 0, rowsTB, DAx, 0.f));
+    RETURN_IF(node_contract(b, DPU, 64, WpU, I, 0, rowsTB, DAx, 1.f));
     RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
     RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
     hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
@@ -530,12 +552,12 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
       CHECK_LAUNCH();
     }
     if (T > 1) {
-      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 0.f));
-      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, (T - 1) * B, DAgBelow + slab * S, 1.f));
+      RETURN_IF(node_contract(b, DPG, 128, WpG, I, 0, (T - 1) * B, DAgBelow + slab * S, 0.f));
+      RETURN_IF(node_contract(b, DPU, 64, WpU, I, 0, (T - 1) * B, DAgBelow + slab * S, 1.f));
     }
     const size_t last = (size_t)(T - 1) * B;
-    RETURN_IF(node_gemm_transposed(b, DPG + last * Np * 128, 128, WpG, I, 0, C, B, DAx, 0.f));
-    RETURN_IF(node_gemm_transposed(b, DPU + last * Np * 64, 64, WpU, I, 0, C, B, DAx, 1.f));
+    RETURN_IF(node_contract(b, DPG + last * Np * 128, 128, WpG, I, 0, B, DAx, 0.f));
+    RETURN_IF(node_contract(b, DPU + last * Np * 64, 64, WpU, I, 0, B, DAx, 1.f));
     RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
     RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
     hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
@@ -656,9 +678,26 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   }
   if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
     const long ld = rup((long)rowsTB * P.C0, 64);
-    MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
-    RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
-    RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
+    // narrow x rows: M = C0 is no GEMM shape; the common widths (flow + time of day, + day of week) and stack sizes
+    // (multi-graph: identity + 3 or 4 dense slots, single graph: + 1) have a dedicated kernel (k_wgrad_narrow)
+    bool narrowDone = true;
+#define WN_LAUNCH(C0_, S_)                                                                                               \
+  hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N), dim3(192), 0, ws, Xall, c.ws + P.oMX0, ld, DPG, DPU, dWpG, \
+                     dWpU, T, B, N, Np, I)
+    if (P.C0 == 2 && S == 4) WN_LAUNCH(2, 4);
+    else if (P.C0 == 2 && S == 5) WN_LAUNCH(2, 5);
+    else if (P.C0 == 2 && S == 2) WN_LAUNCH(2, 2);
+    else if (P.C0 == 2 && S == 1) WN_LAUNCH(2, 1);
+    else if (P.C0 == 9 && S == 4) WN_LAUNCH(9, 4);
+    else narrowDone = false;
+#undef WN_LAUNCH
+    if (narrowDone) {
+      CHECK_LAUNCH();
+    } else {
+      MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
+      RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
+    }
   } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
     for (int t0 = 0; t0 < T;) {
       const int nt = chunk_steps(P, t0);

@@ -697,6 +697,168 @@ __global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, c
   out[idx] = v;
 }
 
+// ---- the chain's node contraction, dedicated kernel ----------------------------------------------------------------
+//   dA[b][s][n][i] (+)= sum_o dPre[b][n][o] * Wp[n][s][iOfs + i][o]        for the 64 hidden columns i of every slot s
+// the transpose of the forward's node-wise contraction (MultiATGCN.py:108), with the forward kernel's structure: one
+// workgroup per (node, 64-row block), the A tile - the pre-activation gradients of the node's rows - in XOR-swizzled
+// LDS, the plain weights read straight from global memory (a lane's B fragment is four consecutive o: one aligned
+// float4 of the plain layout), 16x16x4 MFMA, 4 row tiles x (4 S) column tiles.  GATE: the tile is not read but COMPUTED
+// in the prologue - the gate algebra of the graph cell (what k_chain_cell_gate did as a launch of its own:
+// dzh = slot 0 of the update block's dA + its transposed mix; dh += dzh z; dpg = [dzh h z (1-z) | dr r (1-r)]) - and
+// stored to DPG for the batched part on the way.  Replaces k_chain_cell_gate + two generic k_bgemm launches per step.
+struct ChainNodeArgs {
+  ChainArgs c;           // GATE: operands of the gate algebra (dzhA, dzhMix, hprev, z, r, dr, dh, dpg)
+  const float* dPre;     // !GATE: the pre-activation gradients [rows][Np][O]
+  const float* Wp;       // plain folded weights [N][S][I][O]
+  float* dA;             // [rows][S][Np][64]
+  int I, iOfs, rows, N, Np, S;
+  float beta;            // 1: add to what dA holds (the x-column gradient of the layer above rides in the gate block)
+};
+
+// (grid: x = 64-row block, y = node - the row blocks of one node are neighbours in launch order, so the batched
+// x-column calls, which have 23 row blocks per node, re-read a node's weights from L2.)
+template <bool GATE, int O>
+__global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
+  constexpr int NG = O / 16;
+  static_assert(!GATE || O == 128, "the gate algebra produces the 128 gate columns");
+  __shared__ __attribute__((aligned(16))) float As[(O / 64) * 4096];   // [O/64 chunks][64 rows][16 slots], swizzled
+  const int n = blockIdx.y, rowBase = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int srow = tid >> 4, sq = tid & 15;
+  // ---- weights of this wave's first two column tiles (ct = w, w + 8): they depend on nothing this kernel computes, so
+  // they are requested before the A tile is built and land under the gate algebra ----
+  const int nCt = 4 * p.S;
+  auto wptr = [&](int ct) {
+    const int slot = ct >> 2, i0 = (ct & 3) * 16;
+    return reinterpret_cast<const float4*>(p.Wp + (((size_t)n * p.S + slot) * p.I + p.iOfs + i0 + j) * O) + kq;
+  };
+  float4 wv[2][NG];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4* wp = wptr(min(w + 8 * q, nCt - 1));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wv[q][g] = wp[g * 4];
+  }
+  // ---- A tile ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lr = srow + 32 * it, b = rowBase + lr;
+    const bool ok = b < p.rows;
+    const size_t row = (size_t)min(b, p.rows - 1) * p.Np + n, idx = row * 64 + sq * 4;
+    const int pos = (lr * 16 + (sq ^ (lr & 15))) * 4;
+    if (GATE) {
+      const ChainArgs& a = p.c;
+      float4 dzh = ld4(a.dzhA, (((size_t)min(b, p.rows - 1) * a.S) * a.Np + n) * 64 + sq * 4);
+      if (a.dzhMix)
+        for (int pt = 0; pt < a.mixParts; ++pt) {
+          const float4 m = ld4(a.dzhMix + (size_t)pt * a.mixPartStride, idx);
+          dzh = make_float4(dzh.x + m.x, dzh.y + m.y, dzh.z + m.z, dzh.w + m.w);
+        }
+      const float4 h = a.hprev ? ld4(a.hprev, idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 z = ld4(a.z, idx), r = ld4(a.r, idx), dr = ld4(a.dr, idx), dh = ld4(a.dh, idx);
+      const float4 gz = make_float4(dzh.x * h.x * z.x * (1.f - z.x), dzh.y * h.y * z.y * (1.f - z.y),
+                                    dzh.z * h.z * z.z * (1.f - z.z), dzh.w * h.w * z.w * (1.f - z.w));
+      const float4 gr = make_float4(dr.x * r.x * (1.f - r.x), dr.y * r.y * (1.f - r.y), dr.z * r.z * (1.f - r.z),
+                                    dr.w * r.w * (1.f - r.w));
+      if (ok) {
+        *reinterpret_cast<float4*>(a.dh + idx) = make_float4(dh.x + dzh.x * z.x, dh.y + dzh.y * z.y, dh.z + dzh.z * z.z,
+                                                             dh.w + dzh.w * z.w);
+        *reinterpret_cast<float4*>(a.dpg + row * 128 + sq * 4) = gz;
+        *reinterpret_cast<float4*>(a.dpg + row * 128 + 64 + sq * 4) = gr;
+      }
+      *reinterpret_cast<float4*>(&As[pos]) = gz;             // rows past the batch: garbage in, discarded out (row-local)
+      *reinterpret_cast<float4*>(&As[4096 + pos]) = gr;
+    } else {
+      *reinterpret_cast<float4*>(&As[pos]) = ld4(p.dPre, row * O + sq * 4);
+      if (O == 128) *reinterpret_cast<float4*>(&As[4096 + pos]) = ld4(p.dPre, row * O + 64 + sq * 4);
+    }
+  }
+  __syncthreads();
+  // ---- contraction: column tiles ct = w, w + 8, .. of the 4 S tiles (slot ct >> 2, hidden columns 16 (ct & 3) ..) ----
+  auto tile = [&](int ct, const float4 (&wt)[NG]) {
+    const int slot = ct >> 2, i0 = (ct & 3) * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* buf = As + (g >> 2) * 4096;
+      float4 av[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        av[rt] = *reinterpret_cast<const float4*>(&buf[((rt * 16 + j) * 16 + ((4 * (g & 3) + kq) ^ j)) * 4]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wt[g].x, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wt[g].y, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wt[g].z, acc[rt]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wt[g].w, acc[rt]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b = rowBase + rt * 16 + 4 * kq + e;
+        if (b >= p.rows) continue;
+        float* dst = p.dA + (((size_t)b * p.S + slot) * p.Np + n) * 64 + i0 + j;
+        *dst = p.beta != 0.f ? *dst + acc[rt][e] : acc[rt][e];
+      }
+  };
+  if (w < nCt) tile(w, wv[0]);
+  if (w + 8 < nCt) tile(w + 8, wv[1]);
+  for (int ct = w + 16; ct < nCt; ct += 8) {        // more than 3 dense slots
+    const float4* wp = wptr(ct);
+    float4 wt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wt[g] = wp[g * 4];
+    tile(ct, wt);
+  }
+}
+
+// ---- node-adaptive weight gradients of layer 0's NARROW x rows (C0 = 2..16 input channels) ------------------------
+//   dWpG[n][s][c][o] += sum_rows XA[rows][n][s][c] * dpg[rows][n][o]      (o < 128; dWpU with dpu alike)
+// XA slot 0 = the input rows themselves (time-major x0), slots 1.. = the fold's plain matrix MX0 [(k, n)][ld] with
+// column (b*T + t)*C0 + c.  As a GEMM this has M = C0: a 64 x 64 tile is 97 % padding (the generic kernel spent 1.7 ms
+// on it, at the exposed tail of the backward).  One workgroup per node, one thread per output column o of gate | update
+// (192), S*C0 accumulators each; the pre-activation gradients stream through once, coalesced.
+#define WN_MAXACC 36
+template <int C0, int S>
+__global__ __launch_bounds__(192) void k_wgrad_narrow(const float* __restrict__ x0tm, const float* __restrict__ mx0, long ld,
+                                                      const float* __restrict__ dpg, const float* __restrict__ dpu,
+                                                      float* __restrict__ dWpG, float* __restrict__ dWpU, int T, int B,
+                                                      int N, int Np, int I) {
+  static_assert(S * C0 <= WN_MAXACC, "accumulators live in registers");
+  const int n = blockIdx.x, o = threadIdx.x;
+  const bool gate = o < 128;
+  const int oc = gate ? o : o - 128, O = gate ? 128 : 64;
+  const float* dp = gate ? dpg : dpu;
+  float acc[S][C0];
+#pragma unroll
+  for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) acc[sl][c] = 0.f;
+  for (int t = 0; t < T; ++t)
+    for (int b = 0; b < B; ++b) {
+      const size_t r = (size_t)t * B + b;
+      const float d = dp[(r * Np + n) * O + oc];
+      const float* xs = x0tm + (r * Np + n) * C0;
+      const float* ms = mx0 + (size_t)n * ld + ((size_t)b * T + t) * C0;
+#pragma unroll
+      for (int c = 0; c < C0; ++c) acc[0][c] = fmaf(xs[c], d, acc[0][c]);
+#pragma unroll
+      for (int sl = 1; sl < S; ++sl)
+#pragma unroll
+        for (int c = 0; c < C0; ++c) acc[sl][c] = fmaf(ms[(size_t)(sl - 1) * Np * ld + c], d, acc[sl][c]);
+    }
+  float* dst = gate ? dWpG : dWpU;
+#pragma unroll
+  for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) dst[(((size_t)n * S + sl) * I + c) * O + oc] += acc[sl][c];
+}
+
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
