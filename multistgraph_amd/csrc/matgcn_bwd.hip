@@ -144,15 +144,18 @@ int node_gemm_transposed(const Bwd& b, const float* dPre, int O, const float* Wp
 
 // the same contraction on the dedicated node kernel (64 hidden / input columns per slot, whole 16-byte rows):
 // dA[rows][s][n][0:64] (+)= dPre[rows][n][0:O] . Wp[n][s][iOfs .. iOfs+63][0:O]^T
-int node_contract(const Bwd& b, const float* dPre, int O, const float* Wp, int I, int iOfs, int rows, float* dA, float beta) {
+// (dPreG / WpG: the gate AGCN's 128 columns, dPreU / WpU: the update AGCN's 64 - ONE contraction over all 192, so the
+// output block - 627 MB for the 23 x-column steps of a layer at BM / B = 64 - is written once instead of written, read
+// and written again)
+int node_contract(const Bwd& b, const float* dPreG, const float* WpG, const float* dPreU, const float* WpU, int I,
+                  int iOfs, int rows, float* dA, float beta) {
   const Plan& P = b.c.P;
   ChainNodeArgs cn;
   memset(&cn, 0, sizeof(cn));
-  cn.dPre = dPre; cn.Wp = Wp; cn.dA = dA; cn.I = I; cn.iOfs = iOfs; cn.rows = rows; cn.N = P.N; cn.Np = P.Np; cn.S = b.c.R.S;
-  cn.beta = beta;
+  cn.dPre = dPreG; cn.Wp = WpG; cn.dPre2 = dPreU; cn.Wp2 = WpU; cn.dA = dA; cn.I = I; cn.iOfs = iOfs; cn.rows = rows;
+  cn.N = P.N; cn.Np = P.Np; cn.S = b.c.R.S; cn.beta = beta;
   const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)P.N);
-  if (O == 128) hipLaunchKernelGGL((k_chain_node<false, 128>), grid, dim3(512), 0, b.c.s, cn);
-  else hipLaunchKernelGGL((k_chain_node<false, 64>), grid, dim3(512), 0, b.c.s, cn);
+  hipLaunchKernelGGL((k_chain_node<false, 192>), grid, dim3(512), 0, b.c.s, cn);
   return launch_ok();
 }
 
@@ -532,8 +535,7 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
                        P.Ks > 0 ? MixN : nullptr, DAx, dXall, (size_t)rowsTB, N, Np, C);
     CHECK_LAUNCH();
   } else if (l == 0) {   // a 64-channel input layer: nothing below to ride with
-    RETURN_IF(node_contract(b, DPG, 128, WpG, I, 0, rowsTB, DAx, 0.f));
-    RETURN_IF(node_contract(b, DPU, 64, WpU, I, 0, rowsTB, DAx, 1.f));
+    RETURN_IF(node_contract(b, DPG, WpG, DPU, WpU, I, 0, rowsTB, DAx, 0.f));
     RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
     RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
     hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
@@ -552,12 +554,10 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
       CHECK_LAUNCH();
     }
     if (T > 1) {
-      RETURN_IF(node_contract(b, DPG, 128, WpG, I, 0, (T - 1) * B, DAgBelow + slab * S, 0.f));
-      RETURN_IF(node_contract(b, DPU, 64, WpU, I, 0, (T - 1) * B, DAgBelow + slab * S, 1.f));
+      RETURN_IF(node_contract(b, DPG, WpG, DPU, WpU, I, 0, (T - 1) * B, DAgBelow + slab * S, 0.f));
     }
     const size_t last = (size_t)(T - 1) * B;
-    RETURN_IF(node_contract(b, DPG + last * Np * 128, 128, WpG, I, 0, B, DAx, 0.f));
-    RETURN_IF(node_contract(b, DPU + last * Np * 64, 64, WpU, I, 0, B, DAx, 1.f));
+    RETURN_IF(node_contract(b, DPG + last * Np * 128, WpG, DPU + last * Np * 64, WpU, I, 0, B, DAx, 0.f));
     RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
     RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
     hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
@@ -682,8 +682,8 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
     // (multi-graph: identity + 3 or 4 dense slots, single graph: + 1) have a dedicated kernel (k_wgrad_narrow)
     bool narrowDone = true;
 #define WN_LAUNCH(C0_, S_)                                                                                               \
-  hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N), dim3(192), 0, ws, Xall, c.ws + P.oMX0, ld, DPG, DPU, dWpG, \
-                     dWpU, T, B, N, Np, I)
+  hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N, WN_PARTS), dim3(192 * WN_GROUPS), 0, ws, Xall,          \
+                     c.ws + P.oMX0, ld, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
     if (P.C0 == 2 && S == 4) WN_LAUNCH(2, 4);
     else if (P.C0 == 2 && S == 5) WN_LAUNCH(2, 5);
     else if (P.C0 == 2 && S == 2) WN_LAUNCH(2, 2);

@@ -708,8 +708,10 @@ __global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, c
 // stored to DPG for the batched part on the way.  Replaces k_chain_cell_gate + two generic k_bgemm launches per step.
 struct ChainNodeArgs {
   ChainArgs c;           // GATE: operands of the gate algebra (dzhA, dzhMix, hprev, z, r, dr, dh, dpg)
-  const float* dPre;     // !GATE: the pre-activation gradients [rows][Np][O]
-  const float* Wp;       // plain folded weights [N][S][I][O]
+  const float* dPre;     // !GATE: the pre-activation gradients [rows][Np][O]   (O = 192: the 128 gate columns ...
+  const float* dPre2;    //                                                      ... and here the 64 update columns)
+  const float* Wp;       // plain folded weights [N][S][I][O]                   (O = 192: of the gate AGCN, O = 128 ...
+  const float* Wp2;      //                                                      ... and of the update AGCN, O = 64)
   float* dA;             // [rows][S][Np][64]
   int I, iOfs, rows, N, Np, S;
   float beta;            // 1: add to what dA holds (the x-column gradient of the layer above rides in the gate block)
@@ -725,20 +727,21 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
   const int n = blockIdx.y, rowBase = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int srow = tid >> 4, sq = tid & 15;
-  // ---- weights of this wave's first two column tiles (ct = w, w + 8): they depend on nothing this kernel computes, so
-  // they are requested before the A tile is built and land under the gate algebra ----
+  // ---- weights of this wave's first column tile (ct = w): they depend on nothing this kernel computes, so they are
+  // requested before the A tile is built and land under the gate algebra ----
   const int nCt = 4 * p.S;
-  auto wptr = [&](int ct) {
+  constexpr int O1 = O == 192 ? 128 : O;     // columns of the first operand pair (O = 192: gate 128 | update 64)
+  auto wload1 = [&](int ct, int g) -> float4 {
     const int slot = ct >> 2, i0 = (ct & 3) * 16;
-    return reinterpret_cast<const float4*>(p.Wp + (((size_t)n * p.S + slot) * p.I + p.iOfs + i0 + j) * O) + kq;
+    const size_t wrow = ((size_t)n * p.S + slot) * p.I + p.iOfs + i0 + j;
+    if (O == 192 && g >= O1 / 16) return (reinterpret_cast<const float4*>(p.Wp2 + wrow * 64) + kq)[(g - O1 / 16) * 4];
+    return (reinterpret_cast<const float4*>(p.Wp + wrow * O1) + kq)[g * 4];
   };
-  float4 wv[2][NG];
+  // ONE register set of weights: group g of the next column tile is requested as soon as group g of this one has been
+  // consumed, so the loads of tile ct + 8 fly under the MFMAs of tile ct (two whole sets - 96 registers at O = 192 - spill)
+  float4 wt[NG];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float4* wp = wptr(min(w + 8 * q, nCt - 1));
-#pragma unroll
-    for (int g = 0; g < NG; ++g) wv[q][g] = wp[g * 4];
-  }
+  for (int g = 0; g < NG; ++g) wt[g] = wload1(min(w, nCt - 1), g);
   // ---- A tile ----
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -769,14 +772,16 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
       *reinterpret_cast<float4*>(&As[pos]) = gz;             // rows past the batch: garbage in, discarded out (row-local)
       *reinterpret_cast<float4*>(&As[4096 + pos]) = gr;
     } else {
-      *reinterpret_cast<float4*>(&As[pos]) = ld4(p.dPre, row * O + sq * 4);
-      if (O == 128) *reinterpret_cast<float4*>(&As[4096 + pos]) = ld4(p.dPre, row * O + 64 + sq * 4);
+      *reinterpret_cast<float4*>(&As[pos]) = ld4(p.dPre, row * O1 + sq * 4);
+      if (O1 == 128) *reinterpret_cast<float4*>(&As[4096 + pos]) = ld4(p.dPre, row * O1 + 64 + sq * 4);
+      if (O == 192) *reinterpret_cast<float4*>(&As[2 * 4096 + pos]) = ld4(p.dPre2, row * 64 + sq * 4);
     }
   }
   __syncthreads();
   // ---- contraction: column tiles ct = w, w + 8, .. of the 4 S tiles (slot ct >> 2, hidden columns 16 (ct & 3) ..) ----
-  auto tile = [&](int ct, const float4 (&wt)[NG]) {
+  auto tile = [&](int ct) {
     const int slot = ct >> 2, i0 = (ct & 3) * 16;
+    const int nextCt = min(ct + 8, nCt - 1);
     f32x4 acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -787,14 +792,17 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
         av[rt] = *reinterpret_cast<const float4*>(&buf[((rt * 16 + j) * 16 + ((4 * (g & 3) + kq) ^ j)) * 4]);
+      const float4 wg = wt[g];
+      wt[g] = wload1(nextCt, g);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wt[g].x, acc[rt]);
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wg.x, acc[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wt[g].y, acc[rt]);
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wg.y, acc[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wt[g].z, acc[rt]);
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wg.z, acc[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wt[g].w, acc[rt]);
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wg.w, acc[rt]);
+      __builtin_amdgcn_sched_barrier(0);        // keeps the A reads of later groups from being hoisted (they spilled)
     }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -806,31 +814,26 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
         *dst = p.beta != 0.f ? *dst + acc[rt][e] : acc[rt][e];
       }
   };
-  if (w < nCt) tile(w, wv[0]);
-  if (w + 8 < nCt) tile(w + 8, wv[1]);
-  for (int ct = w + 16; ct < nCt; ct += 8) {        // more than 3 dense slots
-    const float4* wp = wptr(ct);
-    float4 wt[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) wt[g] = wp[g * 4];
-    tile(ct, wt);
-  }
+  for (int ct = w; ct < nCt; ct += 8) tile(ct);
 }
 
 // ---- node-adaptive weight gradients of layer 0's NARROW x rows (C0 = 2..16 input channels) ------------------------
 //   dWpG[n][s][c][o] += sum_rows XA[rows][n][s][c] * dpg[rows][n][o]      (o < 128; dWpU with dpu alike)
 // XA slot 0 = the input rows themselves (time-major x0), slots 1.. = the fold's plain matrix MX0 [(k, n)][ld] with
 // column (b*T + t)*C0 + c.  As a GEMM this has M = C0: a 64 x 64 tile is 97 % padding (the generic kernel spent 1.7 ms
-// on it, at the exposed tail of the backward).  One workgroup per node, one thread per output column o of gate | update
-// (192), S*C0 accumulators each; the pre-activation gradients stream through once, coalesced.
+// on it, at the exposed tail of the backward).  One thread per (node, output column o of gate | update (192), row
+// stream), S*C0 accumulators each; the pre-activation gradients stream through once, coalesced.
 #define WN_MAXACC 36
+#define WN_PARTS 8        // workgroups per node (blockIdx.y), each with WN_GROUPS row groups of 192 threads
+#define WN_GROUPS 4
 template <int C0, int S>
-__global__ __launch_bounds__(192) void k_wgrad_narrow(const float* __restrict__ x0tm, const float* __restrict__ mx0, long ld,
-                                                      const float* __restrict__ dpg, const float* __restrict__ dpu,
-                                                      float* __restrict__ dWpG, float* __restrict__ dWpU, int T, int B,
-                                                      int N, int Np, int I) {
+__global__ __launch_bounds__(192 * WN_GROUPS) void k_wgrad_narrow(const float* __restrict__ x0tm, const float* __restrict__ mx0,
+                                                                  long ld, const float* __restrict__ dpg,
+                                                                  const float* __restrict__ dpu, float* __restrict__ dWpG,
+                                                                  float* __restrict__ dWpU, int T, int B, int N, int Np, int I) {
   static_assert(S * C0 <= WN_MAXACC, "accumulators live in registers");
-  const int n = blockIdx.x, o = threadIdx.x;
+  __shared__ float part[WN_GROUPS - 1][S * C0][192];
+  const int n = blockIdx.x, o = threadIdx.x % 192, rg = threadIdx.x / 192;
   const bool gate = o < 128;
   const int oc = gate ? o : o - 128, O = gate ? 128 : 64;
   const float* dp = gate ? dpg : dpu;
@@ -839,24 +842,39 @@ __global__ __launch_bounds__(192) void k_wgrad_narrow(const float* __restrict__ 
   for (int sl = 0; sl < S; ++sl)
 #pragma unroll
     for (int c = 0; c < C0; ++c) acc[sl][c] = 0.f;
-  for (int t = 0; t < T; ++t)
-    for (int b = 0; b < B; ++b) {
-      const size_t r = (size_t)t * B + b;
-      const float d = dp[(r * Np + n) * O + oc];
-      const float* xs = x0tm + (r * Np + n) * C0;
-      const float* ms = mx0 + (size_t)n * ld + ((size_t)b * T + t) * C0;
+  // the T*B rows are dealt out round robin over (workgroup part, row group): 32 independent streams per node keep
+  // enough loads in flight (one stream per node - 1536 dependent iterations - took 1.06 ms)
+  const int rows = T * B;
+  for (int r = blockIdx.y * WN_GROUPS + rg; r < rows; r += WN_PARTS * WN_GROUPS) {
+    const int t = r / B, b = r - t * B;
+    const float d = dp[((size_t)r * Np + n) * O + oc];
+    const float* xs = x0tm + ((size_t)r * Np + n) * C0;
+    const float* ms = mx0 + (size_t)n * ld + ((size_t)b * T + t) * C0;
 #pragma unroll
-      for (int c = 0; c < C0; ++c) acc[0][c] = fmaf(xs[c], d, acc[0][c]);
+    for (int c = 0; c < C0; ++c) acc[0][c] = fmaf(xs[c], d, acc[0][c]);
 #pragma unroll
-      for (int sl = 1; sl < S; ++sl)
+    for (int sl = 1; sl < S; ++sl)
 #pragma unroll
-        for (int c = 0; c < C0; ++c) acc[sl][c] = fmaf(ms[(size_t)(sl - 1) * Np * ld + c], d, acc[sl][c]);
-    }
+      for (int c = 0; c < C0; ++c) acc[sl][c] = fmaf(ms[(size_t)(sl - 1) * Np * ld + c], d, acc[sl][c]);
+  }
+  if (rg > 0) {
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+      for (int c = 0; c < C0; ++c) part[rg - 1][sl * C0 + c][o] = acc[sl][c];
+  }
+  __syncthreads();
+  if (rg > 0) return;
   float* dst = gate ? dWpG : dWpU;
 #pragma unroll
   for (int sl = 0; sl < S; ++sl)
 #pragma unroll
-    for (int c = 0; c < C0; ++c) dst[(((size_t)n * S + sl) * I + c) * O + oc] += acc[sl][c];
+    for (int c = 0; c < C0; ++c) {
+      float v = acc[sl][c];
+#pragma unroll
+      for (int q = 0; q < WN_GROUPS - 1; ++q) v += part[q][sl * C0 + c][o];
+      unsafeAtomicAdd(&dst[(((size_t)n * S + sl) * I + c) * O + oc], v);
+    }
 }
 
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
