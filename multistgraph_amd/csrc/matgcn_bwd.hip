@@ -194,6 +194,67 @@ int node_weight_grad(const Bwd& b, const float* U, const MixedRows& mr, int Cc, 
   return MATGCN_OK;
 }
 
+// where the forward left the graph mixes of every step of a sequence (see k_wgrad_node): a block per step
+struct StepBlocks {
+  const float* g[MAX_STEPS];
+  long gNode[MAX_STEPS];
+};
+// private blocks [T][N][B][Ks][64] (recurrent rows of the top layer, z*h rows)
+StepBlocks uniform_blocks(const Plan& P, const float* base) {
+  StepBlocks sb;
+  const long gStep = (long)P.N * P.B * P.Ks * H;
+  for (int t = 0; t < P.T; ++t) { sb.g[t] = base + (size_t)t * gStep; sb.gNode[t] = (long)P.B * P.Ks * H; }
+  return sb;
+}
+// the chunk blocks of a hoisted x part: [chunk][N][nt*B][Ks][64]
+StepBlocks chunk_blocks(const Plan& P, const float* base) {
+  StepBlocks sb;
+  const long gStep = (long)P.N * P.B * P.Ks * H;
+  for (int t0 = 0; t0 < P.T;) {
+    const int nt = chunk_steps(P, t0);
+    for (int t = t0; t < t0 + nt; ++t) {
+      sb.g[t] = base + (size_t)t0 * gStep + (size_t)(t - t0) * P.B * P.Ks * H;
+      sb.gNode[t] = (long)nt * P.B * P.Ks * H;
+    }
+    t0 += nt;
+  }
+  return sb;
+}
+// all slots of a node in one workgroup (k_wgrad_node); false = shape outside what the kernel covers
+bool node_wgrad_fast(const Bwd& b, const float* U, const StepBlocks& sb, const float* dPre, int O, int I, int iOfs,
+                     float* dWp, int* rc) {
+  const Plan& P = b.c.P;
+  const int S = b.c.R.S;
+  if (S != P.Ks + 1 || S > 5 || S == 3 || S < 2 || P.T > MAX_STEPS || (O != 128 && O != 64)) return false;
+  WgradNodeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.U = U; a.dPre = dPre; a.dW = dWp + (size_t)iOfs * O;
+  for (int t = 0; t < P.T; ++t) { a.g[t] = sb.g[t]; a.gNode[t] = sb.gNode[t]; }
+  a.T = P.T; a.B = P.B; a.N = P.N; a.Np = P.Np; a.S = S; a.Ks = P.Ks; a.I = I;
+  // parts: enough workgroups for a few full rounds of the chip (2 resident per CU at O = 128, 3 at O = 64) without a
+  // mostly empty last one - at BM (403 nodes, 24 steps): 4 x 403 = 3.1 rounds of 512, 5 x 403 = 2.6 rounds of 768
+  const int parts = O == 128 ? 4 : 5;
+  a.stepsPerPart = P.T >= 8 ? (P.T + parts - 1) / parts : P.T;
+  const dim3 grid((unsigned)P.N, (unsigned)((P.T + a.stepsPerPart - 1) / a.stepsPerPart));
+  const size_t lds = (size_t)2 * WG_KT * ((S * 64 + 16) + (O + 16)) * sizeof(float);
+  const dim3 block((unsigned)(S * O));
+#define WGN(O_, S_, W_) hipLaunchKernelGGL((k_wgrad_node<O_, S_, W_>), grid, block, lds, b.c.s, a)
+  if (O == 128) {
+    if (S == 4) WGN(128, 4, 4);        // 512 threads, 128 registers: two workgroups per compute unit
+    else if (S == 5) WGN(128, 5, 2);
+    else if (S == 2) WGN(128, 2, 4);
+    else return false;
+  } else {
+    if (S == 4) WGN(64, 4, 3);
+    else if (S == 5) WGN(64, 5, 3);
+    else if (S == 2) WGN(64, 2, 3);
+    else return false;
+  }
+#undef WGN
+  *rc = launch_ok();
+  return true;
+}
+
 // dT_j[n][m] += sum_{rows, i} dA[rows][slot 1 + j][n][i] * U[rows][m][i] for the `per` Chebyshev orders of the adaptive
 // adjacency (first-order support 0 is never diagonal: its orders are the dense slots 0 .. per-1)
 int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int Cc, float* dT, bool nodeMajor = false) {
@@ -226,8 +287,9 @@ int linear_weight_grad(const Bwd& b, const float* dPre, int O, const float* In, 
 
 // ---- one backward pass: what its stages share ---------------------------------------------------------------
 struct Pass {
-  Bwd b, bw;                 // bw: the same context on the second stream (weight gradients)
-  hipStream_t s, ws;
+  Bwd b, bw, bx;             // bw: the same context on the second stream (weight gradients), bx: on the x-column stream
+  hipStream_t s, ws, xs;
+  int chunk;                 // steps per x-column chunk of the layers above the first (see bwd_x_chunk)
   bool twoStreams, adp;
   int hT, tOff;              // fnn_off: the head sees the last step only (MultiATGCN.py:412)
   int fusedLds;
@@ -458,6 +520,53 @@ int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
   return MATGCN_OK;
 }
 
+// x columns of both AGCNs and of the residual cell of a layer ABOVE the first, for the steps [t0, t1) its chain has
+// just finished: gradient of the layer's input sequence = of the output of the layer below.  Steps 0..T-2 go into the
+// gate block of the layer below at step t+1 (see mergeAbove); only the sequence's last step, which no step of the
+// layer below follows, is mixed back here.  Runs on the x-column stream beside the rest of the chain (it used to follow
+// the chain on the caller's stream: 2 ms of the critical path at BM / B = 64); the chain of the layer below waits chunk
+// by chunk (bwd_chain).
+int bwd_x_chunk(Pass& pass, const LayerBufs& L, int t0, int t1) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  const Bwd& bx = pass.bx;
+  hipStream_t xs = pass.xs;
+  float* DAgBelow = tr + R.oDAg[(l - 1) & 1];
+  const size_t last = (size_t)(T - 1) * B;
+  if (t1 == T) {   // the first chunk processed: what the whole layer needs once
+    if (twoStreams && l + 1 < P.L) HIP_OK(hipStreamWaitEvent(xs, g_wf.step[1][l + 1], 0));   // the block's readers are done
+    RETURN_IF(zero_async(DAgBelow, slab * S, xs));                                          // step 0: nothing from above
+    if (Np != N) {
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)B * S * (Np - N) * H)), dim3(256), 0, xs, DAx, B * S, N,
+                         Np, H);
+      CHECK_LAUNCH();
+    }
+  }
+  const size_t r0 = (size_t)t0 * B;
+  const int rows = (t1 - t0) * B;
+  RETURN_IF(zero_async(dXall + r0 * Np * C, (long)rows * Np * C, xs));
+  const int tEnd = t1 < T - 1 ? t1 : T - 1;
+  if (tEnd > t0)
+    RETURN_IF(node_contract(bx, DPG + r0 * Np * 128, WpG, DPU + r0 * Np * 64, WpU, I, 0, (tEnd - t0) * B,
+                            DAgBelow + slab * S * (t0 + 1), 0.f));
+  if (t1 == T) {
+    RETURN_IF(node_contract(bx, DPG + last * Np * 128, WpG, DPU + last * Np * 64, WpU, I, 0, B, DAx, 0.f));
+    RETURN_IF(mix_transposed(bx, DAx, B, C, dXall + last * Np * C));
+    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, xs, dXall + last * Np * C, DAx,
+                       (size_t)B, Np, C, S);
+    CHECK_LAUNCH();
+  }
+  {  // residual cell x columns
+    GemmArgs q = gemm_args(DPU2 + r0 * Np * H, RU, dXall + r0 * Np * C, rows * Np, C, H);
+    q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
+    RETURN_IF(gemm(q, 1, xs));
+    GemmArgs q2 = gemm_args(DPG2 + r0 * Np * 128, RG, dXall + r0 * Np * C, rows * Np, C, 128);
+    q2.sAm = 128; q2.sAk = 1; q2.sBk = I; q2.sBn = 1; q2.sCm = C; q2.sCn = 1; q2.beta = 1.f;
+    RETURN_IF(gemm(q2, 1, xs));
+  }
+  return MATGCN_OK;
+}
+
 // the part of a graph layer that is sequential in time
 int bwd_chain(Pass& pass, const LayerBufs& L) {
   PASS_LOCALS(pass);
@@ -478,6 +587,13 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     a.B = B; a.N = N; a.Np = Np; a.S = S;
     a.mixParts = P.Ks > 1 ? P.Ks : 1; a.mixPartStride = slab;     // the transposed mixes arrive split by slot
     const dim3 eg(blocks_for((size_t)slab));
+    if (twoStreams && l + 1 < P.L && (t == T - 1 || (t + 1) % pass.chunk == 0)) {
+      // entering a chunk of the layer above from its top: step t reads the gradient of its output (x columns of the
+      // chunk holding t) and, in its gate block, what rides from step t-1 of the layer above (the chunk holding t-1)
+      const int c0 = t / pass.chunk * pass.chunk;
+      HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][c0], 0));
+      if (c0 > 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][c0 - pass.chunk], 0));
+    }
     {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
       FusedResArgs f;
       f.c = a;
@@ -504,6 +620,15 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     hipLaunchKernelGGL((k_chain_node<true, 128>), ngrid, dim3(512), 0, s, cn);
     CHECK_LAUNCH();
     RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut, true, slab));   // the carry itself is formed by the next step's kernel
+    if (l > 0 && t % pass.chunk == 0) {   // a chunk of steps is through: its x columns start beside the rest of the chain
+      const int t1 = t + pass.chunk < T ? t + pass.chunk : T;
+      if (twoStreams) {
+        HIP_OK(hipEventRecord(g_wf.bready[l][t], s));
+        HIP_OK(hipStreamWaitEvent(pass.xs, g_wf.bready[l][t], 0));
+      }
+      RETURN_IF(bwd_x_chunk(pass, L, t, t1));
+      if (twoStreams) HIP_OK(hipEventRecord(g_wf.bxcol[l][t], pass.xs));
+    }
   }
   if (b.dH0) {   // what step 0 would carry into a step before it: dh + slot 0 of the gate AGCN's dA + its transposed mix
     hipLaunchKernelGGL(k_dh0_out, dim3(blocks_for((size_t)B * N * H)), dim3(256), 0, s, DH, DAg, P.Ks > 0 ? MixOut : nullptr,
@@ -517,13 +642,29 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
 int bwd_x_columns(Pass& pass, const LayerBufs& L) {
   PASS_LOCALS(pass);
   LAYER_LOCALS(L);
+  if (l > 0) return MATGCN_OK;   // the layers above the first did theirs chunk by chunk beside the chain (bwd_x_chunk)
   // ---------------- everything that batches over the T steps ----------------
   // x columns of both AGCNs -> gradient of the input sequence of this layer
   if (narrow) {
     // node-major [s][n][rows][C]: the transposed mix is one GEMM with rows*C columns
     RETURN_IF(zero_async(DAx, (long)rowsTB * S * Np * C, s));
-    RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f, true));
-    RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f, true));
+    bool narrowDone = true;     // the same (C0, S) set as k_wgrad_narrow; any other shape takes the generic GEMM
+#define XN_LAUNCH(C0_, S_)                                                                                               \
+  hipLaunchKernelGGL((k_xcol_narrow<C0_, S_>), dim3((unsigned)((rowsTB + 255) / 256), (unsigned)N), dim3(256), 0, s, DPG, \
+                     DPU, WpG, WpU, DAx, rowsTB, N, Np, I)
+    if (C == 2 && S == 4) XN_LAUNCH(2, 4);
+    else if (C == 2 && S == 5) XN_LAUNCH(2, 5);
+    else if (C == 2 && S == 2) XN_LAUNCH(2, 2);
+    else if (C == 2 && S == 1) XN_LAUNCH(2, 1);
+    else if (C == 9 && S == 4) XN_LAUNCH(9, 4);
+    else narrowDone = false;
+#undef XN_LAUNCH
+    if (narrowDone) {
+      CHECK_LAUNCH();
+    } else {
+      RETURN_IF(node_gemm_transposed(b, DPG, 128, WpG, I, 0, C, rowsTB, DAx, 0.f, true));
+      RETURN_IF(node_gemm_transposed(b, DPU, 64, WpU, I, 0, C, rowsTB, DAx, 1.f, true));
+    }
     const long cols = (long)rowsTB * C;
     float* MixN = tr + R.oMixN;
     if (P.Ks > 0) {
@@ -540,28 +681,6 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
     RETURN_IF(mix_transposed(b, DAx, rowsTB, C, dXall));
     hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)rowsTB * Np * C)), dim3(256), 0, s, dXall, DAx,
                        (size_t)rowsTB, Np, C, S);
-    CHECK_LAUNCH();
-  } else {
-    // layers >= 1: steps 0..T-2 go into the gate block of the layer below at step t+1 (see mergeAbove); only the
-    // sequence's last step, which no step of the layer below follows, is mixed back here
-    const int parBelow = (l - 1) & 1;
-    float* DAgBelow = tr + R.oDAg[parBelow];
-    if (twoStreams && l + 1 < P.L) HIP_OK(hipStreamWaitEvent(s, g_wf.step[1][l + 1], 0));   // its readers are done
-    RETURN_IF(zero_async(DAgBelow, slab * S, s));                                         // step 0: nothing from above
-    if (Np != N) {
-      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)B * S * (Np - N) * H)), dim3(256), 0, s, DAx, B * S, N, Np,
-                         H);
-      CHECK_LAUNCH();
-    }
-    if (T > 1) {
-      RETURN_IF(node_contract(b, DPG, WpG, DPU, WpU, I, 0, (T - 1) * B, DAgBelow + slab * S, 0.f));
-    }
-    const size_t last = (size_t)(T - 1) * B;
-    RETURN_IF(node_contract(b, DPG + last * Np * 128, WpG, DPU + last * Np * 64, WpU, I, 0, B, DAx, 0.f));
-    RETURN_IF(zero_async(dXall, (long)rowsTB * Np * C, s));
-    RETURN_IF(mix_transposed(b, DAx, B, C, dXall + last * Np * C));
-    hipLaunchKernelGGL(k_add_slot0, dim3(blocks_for((size_t)B * Np * C)), dim3(256), 0, s, dXall + last * Np * C, DAx,
-                       (size_t)B, Np, C, S);
     CHECK_LAUNCH();
   }
   {  // residual cell x columns
@@ -651,13 +770,30 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   float* dWpG = tr + R.oDWp[l][0];
   float* dWpU = tr + R.oDWp[l][1];
   const long gStep = (long)N * B * P.Ks * H;
-  if (l + 1 < P.L && P.Ks > 0) {
-    // the mix of h_{t-1} was written into the chunk blocks of the layer above (its x-part mix of step t-1, see
-    // shared_mix_slot): identity slot over all rows, dense slots chunk by chunk, shifted by one step; the mix of
-    // the zero state at t = 0 contributes nothing
+  int rc = MATGCN_OK;
+  // recurrent rows h_{t-1} and their mixes
+  bool fastH = false;
+  if (P.Ks > 0) {
+    StepBlocks sb;
+    if (l + 1 < P.L) {
+      // the mix of h_{t-1} was written into the chunk blocks of the layer above (its x-part mix of step t-1, see
+      // shared_mix_slot): one step off; the mix of the zero state at t = 0 contributes nothing, unless the forward
+      // started from a state: its mix at t = 0 stayed in the workspace block G_l
+      const StepBlocks above = chunk_blocks(P, tr + R.oGX[l + 1]);
+      for (int t = 1; t < T; ++t) { sb.g[t] = above.g[t - 1]; sb.gNode[t] = above.gNode[t - 1]; }
+      sb.g[0] = h0 ? c.ws + P.oG[l] : nullptr; sb.gNode[0] = (long)B * P.Ks * H;
+    } else {
+      sb = uniform_blocks(P, tr + R.oGH[l]);   // the top layer: private blocks [T][N][B][Ks][64]
+    }
+    fastH = node_wgrad_fast(bw, Hprev, sb, DPG, 128, I, C, dWpG, &rc);
+    RETURN_IF(rc);
+  }
+  if (fastH) {
+  } else if (l + 1 < P.L && P.Ks > 0) {
+    // (batched GEMMs: identity slot over all rows, dense slots chunk by chunk)
     MixedRows none = {nullptr, 0, 0, 0, 0, 0, 0};
     RETURN_IF(node_weight_grad(bw, Hprev, none, H, DPG, 128, I, C, 0, rowsTB, dWpG, 1));
-    if (h0) {   // ... unless the forward started from a state: its mix at t = 0 stayed in the workspace block G_l
+    if (h0) {
       MixedRows m0 = {c.ws + P.oG[l], (long)B * P.Ks * H, H, 0, (long)P.Ks * H, 1, B};
       RETURN_IF(node_weight_grad(bw, Hprev, m0, H, DPG, 128, I, C, 0, B, dWpG, 2));
     }
@@ -668,14 +804,16 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
       RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, (long)(t0 + 1) * B, ntm * B, dWpG, 2));
       t0 += nt;
     }
-  } else {  // recurrent rows of the top layer: private blocks [T][N][B][Ks][64]
+  } else {
     MixedRows mh = {tr + R.oGH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
     RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
   }
-  {
+  // z * h rows of the candidate's AGCN
+  if (!(P.Ks > 0 && node_wgrad_fast(bw, ZH, uniform_blocks(P, tr + R.oGZH[l]), DPU, 64, I, C, dWpU, &rc))) {
     MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
     RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
   }
+  RETURN_IF(rc);
   if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
     const long ld = rup((long)rowsTB * P.C0, 64);
     // narrow x rows: M = C0 is no GEMM shape; the common widths (flow + time of day, + day of week) and stack sizes
@@ -698,7 +836,12 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
       RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
       RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
     }
-  } else {       // x rows of deeper layers: one node-major block per x-part chunk of the forward
+  } else if (P.Ks > 0 && node_wgrad_fast(bw, Xall, chunk_blocks(P, tr + R.oGX[l]), DPG, 128, I, 0, dWpG, &rc)) {
+    // x rows of deeper layers (64 channels): the chunk blocks of the forward's hoisted x part
+    RETURN_IF(rc);
+    if (!node_wgrad_fast(bw, Xall, chunk_blocks(P, tr + R.oGX[l]), DPU, 64, I, 0, dWpU, &rc)) return MATGCN_ERR_UNSUPPORTED;
+    RETURN_IF(rc);
+  } else {       // (batched GEMMs: one node-major block per x-part chunk)
     for (int t0 = 0; t0 < T;) {
       const int nt = chunk_steps(P, t0);
       MixedRows mx = {tr + R.oGX[l] + (size_t)t0 * gStep, (long)nt * B * P.Ks * H, H, 0, (long)P.Ks * H, 1, nt * B};
@@ -890,6 +1033,10 @@ int backward_impl(Bwd& b, const float* dOut) {
   q.ws = q.twoStreams ? g_wf.chain[1] : q.s;
   q.bw = b;
   q.bw.c.s = q.ws;
+  q.xs = q.twoStreams ? g_wf.xcol : q.s;
+  q.bx = b;
+  q.bx.c.s = q.xs;
+  q.chunk = P.T >= 8 ? (P.T + 3) / 4 : P.T;
 
   RETURN_IF(bwd_clear(q));
   RETURN_IF(bwd_head(q, dOut));
@@ -917,7 +1064,10 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(bwd_chain(q, L));
       if (q.twoStreams) HIP_OK(hipEventRecord(g_wf.step[0][l], q.s));    // the weight-gradient stream forks here
       RETURN_IF(bwd_x_columns(q, L));
-      if (q.twoStreams) HIP_OK(hipEventRecord(g_wf.mixed[0][l], q.s));   // DAx is complete
+      if (q.twoStreams) {   // DAx is complete (layers above the first: with the top chunk, on the x-column stream)
+        if (l > 0) HIP_OK(hipStreamWaitEvent(q.s, g_wf.bxcol[l][(P.T - 1) / q.chunk * q.chunk], 0));
+        HIP_OK(hipEventRecord(g_wf.mixed[0][l], q.s));
+      }
       RETURN_IF(bwd_layer_weights(q, L, l == 0));
     }
     if (l > 0) cur ^= 1;

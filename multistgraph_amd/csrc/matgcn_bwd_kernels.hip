@@ -817,6 +817,148 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
   for (int ct = w; ct < nCt; ct += 8) tile(ct);
 }
 
+// ---- node-adaptive weight gradients of 64-channel rows: every slot of a node in ONE workgroup ----------------------
+//   dW[n][s][iOfs + i][o] += sum_{(t, b)} XA[t][b][n][s][i] * dPre[t][b][n][o]          (i < 64, o < O)
+// XA slot 0 = the rows themselves (U: [T*B][Np][64]), slots 1.. = their graph mixes where the forward left them: per
+// step t a block g[t] with the node's rows at g[t] + n*gNode[t] + b*Ks*64 (the chunk blocks of the hoisted x part have
+// different sizes, the recurrent rows of a lower layer sit one step off in the blocks of the layer above - a table per
+// step covers all of them; g[t] = null: the mix of that step is zero).
+// As batched GEMMs (one per chunk block, identity slot apart: 47 launches a step at BM) each 64 x 64 tile re-read its
+// pre-activation rows per slot and column tile and the K loops were 64..384 rows short: 43 TFLOP/s.  Here a workgroup
+// owns a node and a range of steps: S*64 x O outputs (wave = slot x 64 columns, 4 x 4 MFMA tiles), both operands staged
+// once per 16 rows through LDS (k-major as they lie in memory: no transposition), partial sums added atomically.
+#define WG_KT 16
+struct WgradNodeArgs {
+  const float* U;
+  const float* dPre;
+  float* dW;                    // at [n = 0][s = 0][iOfs][0]
+  const float* g[64];           // MAX_STEPS
+  long gNode[64];
+  int T, B, N, Np, S, Ks, I, stepsPerPart;
+};
+__device__ __forceinline__ void wg_multiply(const float* Ab, const float* Bb, int AM, int BM, f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int kk = 0; kk < WG_KT / 4; ++kk) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = Ab[4 * kk * AM + 16 * q];
+      bv[q] = Bb[4 * kk * BM + 16 * q];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(av[mt], bv[nt], acc[mt][nt]);
+    __builtin_amdgcn_sched_barrier(0);   // the operand reads of later k groups stay behind these MFMAs (hoisted, they spill)
+  }
+}
+template <int O, int S, int MINW>   // S * O threads (a wave per slot and 64 columns); MINW waves per SIMD the register budget allows
+__global__ __launch_bounds__(S * O, MINW) void k_wgrad_node(WgradNodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wgLds[];
+  // the per-step table is looked up with a per-lane step: from LDS (indexing the kernel argument with a vector index
+  // would make the compiler copy the whole struct to scratch)
+  __shared__ const float* sg[64];
+  __shared__ long sgNode[64];
+  for (int t = 0; t < a.T; ++t)
+    if (threadIdx.x == 0) { sg[t] = a.g[t]; sgNode[t] = a.gNode[t]; }
+  constexpr int AM = S * 64 + 16, BM = O + 16, NT = S * O;
+  float* As = wgLds;                       // [2][WG_KT][AM]   (row stride = 16 mod 64 floats: the four k rows of an
+  float* Bs = wgLds + 2 * WG_KT * AM;      // [2][WG_KT][BM]    operand read land in disjoint banks)
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int ms = w % S, ns = w / S;
+  const int tBeg = blockIdx.y * a.stepsPerPart, tEnd = min(a.T, tBeg + a.stepsPerPart);
+  const int rows = (tEnd - tBeg) * a.B, nTiles = (rows + WG_KT - 1) / WG_KT;
+  constexpr int NA = 256 / O;              // float4 units of A per thread and tile: 16 rows * S*16 units / (S * O threads)
+  constexpr int nbUnits = WG_KT * O / 4;   // of B: 16 rows * O/4 units, ceil(4 / S) per thread
+  constexpr int NB = (4 + S - 1) / S;
+  // two register sets: the rows of tiles t+1 and t+2 are in flight while tile t is multiplied (every row of a node lies
+  // in another page - 106 KB apart - so a load takes long; one tile ahead left the MFMAs waiting: 55 TFLOP/s)
+  float4 ra[2][NA], rb[2][NB];
+  auto fetch = [&](int tile, float4 (&fa)[NA], float4 (&fb)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int u = tid + q * NT, k = u / (S * 16), r = u - k * (S * 16), slot = r >> 4, c4 = r & 15;
+      const int row = tile * WG_KT + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef WGN_LAB_NO_LOAD
+      if (false) {
+#else
+      if (row < rows) {
+#endif
+        const int t = tBeg + row / a.B, b = row - (row / a.B) * a.B;
+        if (slot == 0) v = *reinterpret_cast<const float4*>(a.U + (((size_t)t * a.B + b) * a.Np + n) * 64 + c4 * 4);
+        else if (sg[t]) v = *reinterpret_cast<const float4*>(sg[t] + (size_t)n * sgNode[t] + ((size_t)b * a.Ks + slot - 1) * 64 + c4 * 4);
+      }
+      fa[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int u = tid + q * NT, k = u / (O / 4), c4 = u - k * (O / 4);
+      const int row = tile * WG_KT + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef WGN_LAB_NO_LOAD
+      if (false) {
+#else
+      if (u < nbUnits && row < rows) {
+#endif
+        const int t = tBeg + row / a.B, b = row - (row / a.B) * a.B;
+        v = *reinterpret_cast<const float4*>(a.dPre + (((size_t)t * a.B + b) * a.Np + n) * O + c4 * 4);
+      }
+      fb[q] = v;
+    }
+  };
+  auto stash = [&](int buf, const float4 (&fa)[NA], const float4 (&fb)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int u = tid + q * NT, k = u / (S * 16), r = u - k * (S * 16);
+      *reinterpret_cast<float4*>(&As[(buf * WG_KT + k) * AM + r * 4]) = fa[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int u = tid + q * NT, k = u / (O / 4), c4 = u - k * (O / 4);
+      if (u < nbUnits) *reinterpret_cast<float4*>(&Bs[(buf * WG_KT + k) * BM + c4 * 4]) = fb[q];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (fetch of a tile past the end returns zeros without touching memory)
+  __syncthreads();
+  fetch(0, ra[0], rb[0]);
+  stash(0, ra[0], rb[0]);
+  fetch(1, ra[1], rb[1]);
+  __syncthreads();
+  const float* Ab = As + ms * 64 + j + kq * AM;
+  const float* Bb = Bs + ns * 64 + j + kq * BM;
+  for (int tile = 0; tile < nTiles; tile += 2) {
+    fetch(tile + 2, ra[0], rb[0]);
+#ifndef WGN_LAB_NO_MFMA
+    wg_multiply(Ab, Bb, AM, BM, acc);
+#endif
+    stash(1, ra[1], rb[1]);            // tile + 1
+    __syncthreads();
+    fetch(tile + 3, ra[1], rb[1]);
+#ifndef WGN_LAB_NO_MFMA
+    if (tile + 1 < nTiles) wg_multiply(Ab + WG_KT * AM, Bb + WG_KT * BM, AM, BM, acc);
+#endif
+    stash(0, ra[0], rb[0]);            // tile + 2
+    __syncthreads();
+  }
+  float* dst = a.dW + ((size_t)n * S + ms) * a.I * O + ns * 64 + j;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#ifdef WGN_LAB_NO_ATOMIC
+        if (acc[mt][nt][e] == 12345.678f)
+#endif
+          unsafeAtomicAdd(dst + (size_t)(16 * mt + 4 * kq + e) * O + 16 * nt, acc[mt][nt][e]);
+}
+
 // ---- node-adaptive weight gradients of layer 0's NARROW x rows (C0 = 2..16 input channels) ------------------------
 //   dWpG[n][s][c][o] += sum_rows XA[rows][n][s][c] * dpg[rows][n][o]      (o < 128; dWpU with dpu alike)
 // XA slot 0 = the input rows themselves (time-major x0), slots 1.. = the fold's plain matrix MX0 [(k, n)][ld] with
@@ -875,6 +1017,46 @@ __global__ __launch_bounds__(192 * WN_GROUPS) void k_wgrad_narrow(const float* _
       for (int q = 0; q < WN_GROUPS - 1; ++q) v += part[q][sl * C0 + c][o];
       unsafeAtomicAdd(&dst[(((size_t)n * S + sl) * I + c) * O + oc], v);
     }
+}
+
+// ---- x-column gradients of layer 0's NARROW input (the transposed counterpart of k_wgrad_narrow) -----------------
+//   dA[s][n][row][c] = sum_o dpg[row][n][o] WpG[n][s][c][o] + sum_o dpu[row][n][o] WpU[n][s][c][o]        (c < C0)
+// node-major output (the transposed mix then is ONE GEMM with rows*C0 columns).  As a GEMM this has N = C0 output
+// columns per slot: the generic kernel spent 2 x 0.58 ms on 97 % padding.  Here: one thread per (node, row), the S*C0
+// weights of every o broadcast from LDS, the 192 pre-activation gradients of the row read once as float4.
+template <int C0, int S>
+__global__ __launch_bounds__(256) void k_xcol_narrow(const float* __restrict__ dpg, const float* __restrict__ dpu,
+                                                     const float* __restrict__ WpG, const float* __restrict__ WpU,
+                                                     float* __restrict__ dA, int rows, int N, int Np, int I) {
+  constexpr int SC = S * C0, SCP = (SC + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float wl[192 * SCP];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  for (int e = tid; e < 192 * SC; e += 256) {
+    const int o = e % 192, sc = e / 192, sl = sc / C0, c = sc - sl * C0;
+    const size_t wrow = ((size_t)n * S + sl) * I + c;
+    wl[o * SCP + sc] = o < 128 ? WpG[wrow * 128 + o] : WpU[wrow * 64 + o - 128];
+  }
+  __syncthreads();
+  const int row = blockIdx.x * 256 + tid;
+  if (row >= rows) return;
+  float acc[SC];
+#pragma unroll
+  for (int i = 0; i < SC; ++i) acc[i] = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(dpg + ((size_t)row * Np + n) * 128);
+  const float4* u4 = reinterpret_cast<const float4*>(dpu + ((size_t)row * Np + n) * 64);
+  auto fold = [&](float d, int o) {
+#pragma unroll
+    for (int i = 0; i < SC; ++i) acc[i] = fmaf(d, wl[o * SCP + i], acc[i]);
+  };
+#pragma unroll 4
+  for (int q = 0; q < 48; ++q) {
+    const float4 d = q < 32 ? g4[q] : u4[q - 32];
+    fold(d.x, 4 * q); fold(d.y, 4 * q + 1); fold(d.z, 4 * q + 2); fold(d.w, 4 * q + 3);
+  }
+#pragma unroll
+  for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) dA[(((size_t)sl * Np + n) * rows + row) * C0 + c] = acc[sl * C0 + c];
 }
 
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row

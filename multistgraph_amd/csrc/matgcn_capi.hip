@@ -293,6 +293,9 @@ struct Wavefront {
   hipStream_t xpart[MATGCN_MAX_LAYERS];
   hipEvent_t fork, done[MATGCN_MAX_LAYERS];
   hipStream_t aux;                                 // parameter-only side work of forward_train (plain copies for the backward)
+  hipStream_t xcol;                                // backward: x-column gradients of a layer, chunk by chunk beside its chain
+  hipEvent_t bready[MATGCN_MAX_LAYERS][MAX_STEPS]; // backward: the chain of layer l has finished step t (a chunk's lowest)
+  hipEvent_t bxcol[MATGCN_MAX_LAYERS][MAX_STEPS];  // backward: the x columns of layer l's chunk starting at step t are done
   hipEvent_t auxFork, auxDone;
   hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
@@ -325,6 +328,7 @@ int wavefront_ready() {
   }
   HIP_OK(hipEventCreateWithFlags(&g_wf.fork, hipEventDisableTiming));
   HIP_OK(hipStreamCreateWithFlags(&g_wf.aux, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&g_wf.xcol, hipStreamNonBlocking));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxFork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxDone, hipEventDisableTiming));
   for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
@@ -333,6 +337,8 @@ int wavefront_ready() {
       HIP_OK(hipEventCreateWithFlags(&g_wf.step[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.xdone[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.mixed[l][t], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_wf.bready[l][t], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_wf.bxcol[l][t], hipEventDisableTiming));
     }
   }
 

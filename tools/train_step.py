@@ -1,5 +1,6 @@
 """Training steps of the bench workload (default Baltimore 403, B=64): forward_train + backward through the plugin
-surface (calculate_loss().backward()), timed with HIP events.  usage: train_step.py [workload] [steps]"""
+surface (calculate_loss().backward()), timed with HIP events.  usage: train_step.py [workload] [steps] [serial]
+(serial: matgcn_set_wavefront(0) - every kernel alone on one stream, so a profiler's durations are the kernels' own)"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +13,9 @@ w = dict(bench.WORKLOADS[name])
 dev = torch.device("cuda:0")
 model, df, cfg = bench.build_model(w, dev, 0)
 model.train()
+if len(sys.argv) > 3 and sys.argv[3] == "serial":
+    from multistgraph_amd import _lib
+    _lib.load().matgcn_set_wavefront(0)
 x_np, y_np = syn.make_batch_arrays(w["batch"], w["nodes"], w["out"], 0, feat=2)
 batch = {"X": torch.from_numpy(x_np).to(dev), "y": torch.from_numpy(y_np).to(dev)}
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
