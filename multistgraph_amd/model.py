@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import graph_prep
+from . import hidden_pad
 from .ops import HotPath, PathSpec, diagonal_mask, masked_mae_device, masked_mae_loss, spec_from_config
 
 try:  # inside a LibCity checkout: subclass the real plugin base so isinstance checks hold
@@ -154,6 +155,10 @@ class MultiATGCN(AbstractTrafficStateModel):
         self.end_dim = get("end_dim", 1)
         self.load_dynamic = get("load_dynamic", False)
         self.hidden_dim = get("rnn_units", 64)
+        if self.hidden_dim > hidden_pad.WIDTH:
+            raise NotImplementedError("rnn_units = %d: the HIP kernels hold 64 hidden channels; narrower models run on "
+                                      "them zero-padded (hidden_pad.py), wider ones are not built" % self.hidden_dim)
+        self._padded = self.hidden_dim < hidden_pad.WIDTH   # parameters keep the reference's shapes; the kernels see 64
         self.num_layers = get("num_layers", 2)
         assert self.num_layers >= 1, "At least one recurrent layer in the encoder"
         if self.add_day_in_week and not self.add_time_in_day:
@@ -196,7 +201,7 @@ class MultiATGCN(AbstractTrafficStateModel):
             self.node_emb = nn.Parameter(torch.randn(n, embed_dim_cfg))
         self.node_vec1 = nn.Parameter(torch.empty(n, rank))
         self.node_vec2 = nn.Parameter(torch.empty(rank, n))
-        self.spec: PathSpec = spec_from_config(config, data_feature, n, rank,
+        self.spec: PathSpec = spec_from_config(dict(config, rnn_units=hidden_pad.WIDTH), data_feature, n, rank,
                                                0 if not use_static else len(mats),
                                                diagonal_mask(self._static_host))
         self.output_dim = self.spec.out_dim
@@ -234,7 +239,8 @@ class MultiATGCN(AbstractTrafficStateModel):
 
     # ---- hot path plumbing ----------------------------------------------------------------------
     def _state(self) -> Dict[str, torch.Tensor]:
-        return {k: v.detach() for k, v in self.named_parameters()}
+        state = {k: v.detach() for k, v in self.named_parameters()}
+        return hidden_pad.pad_state(state, self.hidden_dim, self.feature_final) if self._padded else state
 
     def _initial_state(self, batch: int) -> Optional[torch.Tensor]:
         """(L, B, N, H) initial encoder state from the static features, or None (zeros): a PCA of the static table and
@@ -277,7 +283,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         enabled the training form (activations kept, HIP backward behind torch autograd)."""
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         h0 = self._initial_state(batch)
-        h0 = None if h0 is None else h0.contiguous()
+        h0 = None if h0 is None else (hidden_pad.pad_last(h0) if self._padded else h0.contiguous())
         hp = self._path_for_batch(batch, device)
         if not needs_grad:
             if self.training:
@@ -292,8 +298,13 @@ class MultiATGCN(AbstractTrafficStateModel):
             mask = nn.functional.dropout(torch.ones(batch, 1 if self.fnn_off else self.input_window,
                                                     self.num_nodes, self.hidden_dim, device=device),
                                          p=0.1, training=True)   # fnn_off keeps the last step only (:412)
+            if self._padded:
+                mask = hidden_pad.pad_last(mask)
         # static_initial_* are host-side torch layers: their gradients flow through h0, not through the HIP backward
         named = [(k, p) for k, p in self.named_parameters() if not k.startswith("static_initial")]
+        if self._padded:   # differentiable zero-padding: autograd slices the gradients back into the real parameters
+            padded = hidden_pad.pad_state(dict(named), self.hidden_dim, self.feature_final)
+            named = [(k, padded[k]) for k, _ in named]
         return _TrainStep.apply(hp, source, mask, h0, tuple(k for k, _ in named), *[p for _, p in named])
 
     def forward(self, batch):

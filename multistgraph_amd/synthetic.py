@@ -161,10 +161,12 @@ def param_shapes(n: int, *, out_steps: int, hidden: int = 64, layers: int = 2,
                  embed_dim_node: int = 20, embed_dim_adj: int = 20, feat_in: int = 2,
                  out_dim: int = 1, k_total: int = 5, len_ts: int = 4, in_steps: int = 24,
                  adj_rank: int | None = None, gcn_off: bool = False, fnn_off: bool = False,
-                 node_specific_off: bool = False, static: bool = False) -> dict:
+                 node_specific_off: bool = False, static: bool = False, rnn_units: int | None = None) -> dict:
     """The checkpoint ABI of the reference model (MultiATGCN.py:285-344), including the
     ablation switches: gcn_off puts dense GRU cells into encoder.agru_cells and drops res_cells (:177-192),
     fnn_off convolves the last step only (:342-344), node_specific_off shrinks the node embedding to 1 (:350-354)."""
+    if rnn_units is not None:   # the config key of the reference (MultiATGCN.py:322)
+        hidden = rnn_units
     r = min(n, embed_dim_adj) if adj_rank is None else adj_rank
     d = 1 if node_specific_off else embed_dim_node
     shapes = {

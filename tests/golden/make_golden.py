@@ -208,6 +208,19 @@ for nm, flags in (("gcnoff", {"gcn_off": True}), ("fnnoff", {"fnn_off": True}),
     CASES.append(dict(name="abl_%s" % nm, nodes=21, batch=3, out=6, feat=2, adjtype="multi",
                       adpadj="unidirection", cheb=2, seed=10, flags=flags))
 
+# rnn_units below the default 64 (MultiATGCN.py:322; the commented sweep of run_model_parameter.py:11 lists 16, 32, 64,
+# 72): the plugin runs them zero-padded on the 64-wide kernels (multistgraph_amd/hidden_pad.py)
+CASES.append(dict(name="hid32_multi_uni_c2", nodes=21, batch=2, out=3, feat=2, adjtype="multi",
+                  adpadj="unidirection", cheb=2, seed=10, flags={"rnn_units": 32}))
+CASES.append(dict(name="hid16_od_non_c3", nodes=21, batch=3, out=6, feat=2, adjtype="od",
+                  adpadj="none", cheb=3, seed=100, flags={"rnn_units": 16}))
+CASES.append(dict(name="hid32_multi_uni_c2_static", nodes=21, batch=2, out=3, feat=2, adjtype="multi",
+                  adpadj="unidirection", cheb=2, seed=10, static_dim=24, flags={"rnn_units": 32}))
+CASES.append(dict(name="hid48_gcnoff", nodes=21, batch=3, out=6, feat=2, adjtype="multi",
+                  adpadj="unidirection", cheb=2, seed=10, flags={"rnn_units": 48, "gcn_off": True}))
+CASES.append(dict(name="hid32_fnnoff_dyn7", nodes=19, batch=2, out=6, feat=7, adjtype="multi",
+                  adpadj="bidirection", cheb=2, seed=1000, flags={"rnn_units": 32, "fnn_off": True}))
+
 
 def main():
     only = set(sys.argv[1:])

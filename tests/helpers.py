@@ -13,7 +13,8 @@ with open(os.path.join(GOLDEN_DIR, "index.json")) as fh:
 
 TINY = sorted(k for k in INDEX if k.startswith("tiny_"))
 BIG = sorted(k for k in INDEX if INDEX[k].get("big"))      # N = 4096: prediction only, static supports subsampled
-FULL = sorted(k for k in INDEX if not k.startswith("tiny_") and k not in BIG)
+HID = sorted(k for k in INDEX if k.startswith("hid"))      # rnn_units < 64: through the plugin class only (hidden_pad)
+FULL = sorted(k for k in INDEX if not k.startswith("tiny_") and k not in BIG and k not in HID)
 
 
 class Case:
@@ -36,16 +37,20 @@ class Case:
         self.x, self.y = syn.make_batch_arrays(self.b, self.n, self.out, self.seed, feat=self.feat)
 
     def config(self, device="cpu"):
-        return dict(input_window=24, output_window=self.out, add_time_in_day=True, add_day_in_week=False,
-                    load_dynamic=self.feat > 2, adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb,
-                    embed_dim_node=20, embed_dim_adj=20, rnn_units=64, num_layers=2, device=torch.device(device),
-                    batch_size=self.b, **self.flags)
+        cfg = dict(input_window=24, output_window=self.out, add_time_in_day=True, add_day_in_week=False,
+                   load_dynamic=self.feat > 2, adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb,
+                   embed_dim_node=20, embed_dim_adj=20, rnn_units=64, num_layers=2, device=torch.device(device),
+                   batch_size=self.b)
+        cfg.update(self.flags)
+        return cfg
 
     def oracle_cfg(self):
-        return dict(adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb, num_layers=2, rnn_units=64,
-                    len_closeness=48, len_period=24, len_trend=24, output_window=self.out, input_window=24,
-                    add_time_in_day=True, add_day_in_week=False, load_dynamic=self.feat > 2, start_dim=0,
-                    end_dim=1, **self.flags)
+        cfg = dict(adjtype=self.adjtype, adpadj=self.adpadj, cheb_order=self.cheb, num_layers=2, rnn_units=64,
+                   len_closeness=48, len_period=24, len_trend=24, output_window=self.out, input_window=24,
+                   add_time_in_day=True, add_day_in_week=False, load_dynamic=self.feat > 2, start_dim=0,
+                   end_dim=1)
+        cfg.update(self.flags)
+        return cfg
 
     def h0(self, layers=2, batch=None):
         """(L, B, N, H) initial state of the static-feature cases as the reference computed it, else None"""

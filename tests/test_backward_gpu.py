@@ -160,7 +160,8 @@ def test_backward_matches_oracle_autograd(name, fold, lib_built):
     assert not bad, bad
 
 
-GRAD_CASES = sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("grad_"))
+# (grad_hid*: rnn_units < 64 runs through the plugin class only - tests/test_hidden_pad.py)
+GRAD_CASES = sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("grad_") and not f.startswith("grad_hid"))
 
 
 def _check_against_fixture(gold, grads, tol=GRAD_TOL):

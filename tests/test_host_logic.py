@@ -167,6 +167,7 @@ def _reference_model_class():
     ("abl_gcnoff", {}), ("abl_fnnoff", {}), ("abl_nodeoff", {}), ("abl_gcnfnnoff", {}),
     ("tiny_multi_uni_c2", {"cheb_order": 1}), ("tiny_od_non_c2", {"cheb_order": 1}),
     ("tiny_multi_uni_c2", {"static_dim": 24}), ("tiny_cosine_non_c2", {"static_dim": 30}),
+    ("tiny_multi_uni_c2", {"rnn_units": 32}), ("tiny_od_non_c2", {"rnn_units": 16, "static_dim": 24}),
 ])
 def test_same_seed_gives_the_reference_initial_weights(name, extra):
     """_init_parameters (MultiATGCN.py:356-361) AND the RNG stream in front of it (:296 randn,

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FULL, GOLDEN_DIR, TINY, Case, max_norm_err
+from helpers import FULL, GOLDEN_DIR, HID, TINY, Case, max_norm_err
 from oracle import matgcn_oracle as O
 
 TOL = 1e-5
@@ -22,12 +22,12 @@ def _static_h0(c, p, dtype=torch.float32):
     return O.static_initial_state(torch.as_tensor(c.static).to(dtype), torch.as_tensor(c.gold["pca_v"]).to(dtype), p)
 
 
-@pytest.mark.parametrize("name", TINY + FULL)
+@pytest.mark.parametrize("name", TINY + FULL + HID)
 def test_inputs_regenerate_identically(name):
     assert Case(name).checksums_ok()
 
 
-@pytest.mark.parametrize("name", TINY + FULL)
+@pytest.mark.parametrize("name", TINY + FULL + HID)
 def test_static_supports(name):
     c = Case(name)
     mats = O.static_supports(c.data_feature["adj_mx"], c.data_feature["coordinate"], c.static, c.adjtype)
@@ -89,7 +89,7 @@ def test_stages_tiny(name):
     del use_static
 
 
-@pytest.mark.parametrize("name", TINY + FULL)
+@pytest.mark.parametrize("name", TINY + FULL + HID)
 def test_prediction_loss_and_mae(name):
     c = Case(name)
     g = c.gold
@@ -134,11 +134,12 @@ def test_oracle_autograd_matches_reference_gradients(name):
     statics = orc.supports_as_tensors(c.gold["static_supports"], torch.float64) if use_static else []
     cfg = c.oracle_cfg()
     x0 = orc.fuse_heads(torch.tensor(c.x, dtype=torch.float64), p, cfg)
-    init = torch.zeros(2, c.b, c.n, 64, dtype=torch.float64)
+    init = torch.zeros(2, c.b, c.n, c.flags.get("rnn_units", 64), dtype=torch.float64)
     h0 = _static_h0(c, p, torch.float64)       # its gradient reaches static_initial_gru.embd.*
     if h0 is not None:
         init = h0.expand(2, c.b, -1, -1)
-    seq, _ = orc.encoder(x0, init, p, statics, cfg["adjtype"], cfg["adpadj"], cfg["cheb_order"], 2, faithful=False)
+    seq, _ = orc.encoder(x0, init, p, statics, cfg["adjtype"], cfg["adpadj"], cfg["cheb_order"], 2, faithful=False,
+                         gcn_off=bool(cfg.get("gcn_off", False)))
     y = orc.output_head(seq * torch.tensor(mask), p, c.out, 1)
     assert max_norm_err(y.detach().numpy(), gold["pred"]) <= 1e-5
     (y * torch.tensor(gold["d_out"], dtype=torch.float64)).sum().backward()
