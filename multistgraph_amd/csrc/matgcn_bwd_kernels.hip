@@ -29,13 +29,16 @@ struct GemmArgs {
   int mode, split;
 };
 
-#define BG_LD 80   // LDS row pitch (floats): lanes with kq = 0..3 land 16 banks apart
-// column swizzle of the staged tiles: element (k, x) lives in column x ^ (16 * ((k >> 2) & 3)).  A thread that loaded
-// four CONSECUTIVE k of one row (K-contiguous operands: pre-activation gradients, plain weights) writes rows k, k+1, ..
-// and the four threads that share a row write rows 4 apart - 64 floats apart at this pitch, i.e. the SAME bank; the
-// swizzle spreads them over the four 16-bank groups, and the fragment reads (k = 4 s + kq: the term is 16 * (s & 3),
-// wave-uniform) stay conflict-free.  Round 1 measured half of this kernel's LDS-active cycles as bank conflicts.
-#define BG_SWZ(k) ((((k) >> 2) & 3) << 4)
+#define BG_LD 80   // LDS row pitch (floats): 80 = 16 mod 32, so k and k + 1 sit half a bank row apart
+// column swizzle of the staged tiles: element (k, x) lives in column x ^ (8 * ((k >> 2) & 3)).  ds_write_b32 and
+// ds_read_b32 bank by (address / 4) mod 32 within each 32-lane half of the wave (MI355X_MICROARCH.md, LDS).  A thread that
+// loaded four CONSECUTIVE k of one row (K-contiguous operands: pre-activation gradients, plain weights) writes rows k,
+// k+1, ..; the four threads that share a row write rows 4 apart - 320 floats apart at this pitch, i.e. the SAME bank -
+// and a 32-lane half holds 8 rows x 4 such threads: XOR-ing 8 * (k quad) into the column spreads them over the 32 banks
+// (round 2 first used 16 * (k quad): exact for 64 banks, still two-way for the 32 of a b32 access - PMC showed 30-47 % of
+// the LDS-active cycles as conflicts).  The fragment reads (k = 4 s + kq: the term is 8 * (s & 3), wave-uniform; kq = 0 / 1
+// of a half differ by one row = 16 banks) stay conflict-free.
+#define BG_SWZ(k) ((((k) >> 2) & 3) << 3)
 #ifndef BG_KH
 #define BG_KH 1    // 16-wide K halves per staged tile (2 was measured: no gain at the backward's shapes, twice the LDS)
 #endif
@@ -87,9 +90,11 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ra[BG_KH][4], rb[BG_KH][4];
+  // two register sets: K-tiles t+1 and t+2 are in flight while tile t is multiplied (one tile ahead - 16 MFMAs per wave -
+  // cannot cover a memory round trip; the loop is unrolled by two so that the sets stay named registers)
+  float ra[2][BG_KH][4], rb[2][BG_KH][4];
   int fk2 = tBeg / kTiles, fkt = tBeg - fk2 * kTiles;   // (k2, k tile) of the next fetch: advanced, never divided again
-  auto fetch = [&]() {
+  auto fetch = [&](float (&fa)[BG_KH][4], float (&fb)[BG_KH][4]) __attribute__((always_inline)) {
     const int k2 = fk2, kBase = fkt * BG_KT;
     if (++fkt == kTiles) { fkt = 0; ++fk2; }
     const float* Ap = A + (size_t)k2 * g.sAk2;
@@ -101,60 +106,79 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
       const bool fullA = vecA && m0 + am[3] < g.M && k0 + ak[3] < g.K;
       if (fullA) {
         const float4 v = *reinterpret_cast<const float4*>(Ap + (size_t)(m0 + am[0]) * g.sAm + (size_t)(k0 + ak[0]) * g.sAk);
-        ra[h][0] = v.x; ra[h][1] = v.y; ra[h][2] = v.z; ra[h][3] = v.w;
+        fa[h][0] = v.x; fa[h][1] = v.y; fa[h][2] = v.z; fa[h][3] = v.w;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = m0 + am[i], k = k0 + ak[i];
-          ra[h][i] = (m < g.M && k < g.K) ? Ap[(size_t)m * g.sAm + (size_t)k * g.sAk] : 0.f;
+          fa[h][i] = (m < g.M && k < g.K) ? Ap[(size_t)m * g.sAm + (size_t)k * g.sAk] : 0.f;
         }
       }
       const bool fullB = vecB && n0 + bn[3] < g.N && k0 + bk[3] < g.K;
       if (fullB) {
         const float4 v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + bk[0]) * g.sBk + (size_t)(n0 + bn[0]) * g.sBn);
-        rb[h][0] = v.x; rb[h][1] = v.y; rb[h][2] = v.z; rb[h][3] = v.w;
+        fb[h][0] = v.x; fb[h][1] = v.y; fb[h][2] = v.z; fb[h][3] = v.w;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int n = n0 + bn[i], kb = k0 + bk[i];
-          rb[h][i] = (n < g.N && kb < g.K) ? Bp[(size_t)kb * g.sBk + (size_t)n * g.sBn] : 0.f;
+          fb[h][i] = (n < g.N && kb < g.K) ? Bp[(size_t)kb * g.sBk + (size_t)n * g.sBn] : 0.f;
         }
       }
     }
   };
-  auto stash = [&](int buf) {
+  // (operands that are unit-stride along M / N hold four consecutive columns of ONE k row: a single 16-byte store)
+  const bool rowA = vecA && !aK, rowB = vecB && bN;
+  auto stash = [&](int buf, const float (&fa)[BG_KH][4], const float (&fb)[BG_KH][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < BG_KH; ++h)
+    for (int h = 0; h < BG_KH; ++h) {
+      if (rowA) {
+        *reinterpret_cast<float4*>(&As[buf][16 * h + ak[0]][am[0] ^ BG_SWZ(ak[0])]) =
+            make_float4(fa[h][0], fa[h][1], fa[h][2], fa[h][3]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        As[buf][16 * h + ak[i]][am[i] ^ BG_SWZ(ak[i])] = ra[h][i];
-        Bs[buf][16 * h + bk[i]][bn[i] ^ BG_SWZ(bk[i])] = rb[h][i];
+        for (int i = 0; i < 4; ++i) As[buf][16 * h + ak[i]][am[i] ^ BG_SWZ(ak[i])] = fa[h][i];
       }
+      if (rowB) {
+        *reinterpret_cast<float4*>(&Bs[buf][16 * h + bk[0]][bn[0] ^ BG_SWZ(bk[0])]) =
+            make_float4(fb[h][0], fb[h][1], fb[h][2], fb[h][3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[buf][16 * h + bk[i]][bn[i] ^ BG_SWZ(bk[i])] = fb[h][i];
+      }
+    }
+  };
+  auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4 * BG_KH; ++s) {
+      const int k = 4 * s + kq;
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = As[buf][k][(wm * 32 + a * 16 + j) ^ ((s & 3) << 3)];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = Bs[buf][k][(wn * 32 + b * 16 + j) ^ ((s & 3) << 3)];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a], bv[b], acc[a][b]);
+    }
   };
   if (tBeg < tEnd) {
-    fetch();
-    stash(0);
+    fetch(ra[0], rb[0]);                               // tile tBeg
+    stash(0, ra[0], rb[0]);
+    if (tBeg + 1 < tEnd) fetch(ra[1], rb[1]);          // tile tBeg + 1
     __syncthreads();
-    int buf = 0;
-    for (int tile = tBeg; tile < tEnd; ++tile) {
-      const bool more = tile + 1 < tEnd;
-      if (more) fetch();
-#pragma unroll
-      for (int s = 0; s < 4 * BG_KH; ++s) {
-        const int k = 4 * s + kq;
-        float av[2], bv[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = As[buf][k][(wm * 32 + a * 16 + j) ^ ((s & 3) << 4)];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) bv[b] = Bs[buf][k][(wn * 32 + b * 16 + j) ^ ((s & 3) << 4)];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(av[a], bv[b], acc[a][b]);
-      }
-      if (more) stash(buf ^ 1);
+    for (int tile = tBeg; tile < tEnd; tile += 2) {
+      if (tile + 2 < tEnd) fetch(ra[0], rb[0]);        // tile + 2
+      mma(0);
+      if (tile + 1 < tEnd) stash(1, ra[1], rb[1]);     // tile + 1
       __syncthreads();
-      buf ^= 1;
+      if (tile + 1 < tEnd) {
+        if (tile + 3 < tEnd) fetch(ra[1], rb[1]);      // tile + 3
+        mma(1);
+        if (tile + 2 < tEnd) stash(0, ra[0], rb[0]);   // tile + 2
+        __syncthreads();
+      }
     }
   }
 #pragma unroll
@@ -497,6 +521,8 @@ __device__ __forceinline__ float get4(const float4& v, int x) { return x == 0 ? 
 // 64 rows are 1.6 per CU, too few to keep enough loads in flight).  The staged tile is k-major; row x of reduction
 // index k lives in column (x + 4 * (k >> 2)) & 63: the threads of phase 1 hold FOUR consecutive k of one row and the
 // 16 threads that share a row hold k-quads 16 rows apart - without the rotation all of them write into one bank.
+// (A ds_write_b32 banks by 32 within each 32-lane half, so quads q and q + 8 still meet - PMC: a third of the LDS-active
+// cycles; a rotation of 2 per quad removes that and was measured SLOWER, 47.4 vs 43.4 us: the kernel is not LDS-bound.)
 #define CF_ROT(k) (4 * ((k) >> 2))
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_chain_res_fused(FusedResArgs f) {

@@ -3,7 +3,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r02m
-python -m pytest tests/test_backward_gpu.py -x -q -m gpu -k "bm_small or plugin or series or h0 or static or synthetic or golden or reference" > $R/gpurun_out/r02m/pytest.log 2>&1
+python -m pytest tests/test_backward_gpu.py -x -q -m gpu -k "bm_small or plugin or series or h0 or static or synthetic or golden or reference or gemm" > $R/gpurun_out/r02m/pytest.log 2>&1
 echo "pytest rc=$?"; tail -2 $R/gpurun_out/r02m/pytest.log
 python3 $R/tools/host_enqueue_time.py bm403 6 2>&1 | tail -3
 export TMPDIR=/tmp
