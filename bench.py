@@ -33,6 +33,7 @@ Rank 0 prints ONE JSON line.  Two extra objects:
                  host's cores on the same workload (rank 0, N=1 only).
 """
 import argparse
+import datetime
 import ctypes as C
 import json
 import os
@@ -201,7 +202,7 @@ def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     return out
 
 
-def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None):
+def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None, ctl=None):
     """One optimisation step as TrafficStateExecutor._train_epoch runs it (traffic_state_executor.py:411-422):
     loss = model.calculate_loss(batch); loss.backward(); optimizer.step() - forward_train + backward on the HIP
     path, Adam in torch.  With more than one rank every rank steps on its own batch shard and the
@@ -215,11 +216,25 @@ def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None):
     fwd, bwd, red, adam, losses = [], [], [], [], []
     for i in range(warm + steps):
         opt.zero_grad()
-        ev[0].record()
-        loss = model.calculate_loss(batch)
-        ev[1].record()
-        loss.backward()
-        ev[2].record()
+        failure = None
+        try:
+            ev[0].record()
+            loss = model.calculate_loss(batch)
+            ev[1].record()
+            loss.backward()
+            ev[2].record()
+        except Exception as exc:   # noqa: BLE001
+            if world == 1 or i > 0:
+                raise
+            failure = exc
+        if world > 1 and i == 0:
+            # the gradient exchange is a collective: a rank that failed its local step must not leave the others waiting
+            # in it.  Every rank votes on a CPU (gloo) control group first; one failure makes ALL ranks give the section up.
+            import torch.distributed as dist
+            vote = torch.tensor([0 if failure is not None else 1], dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=ctl)
+            if int(vote.item()) == 0:
+                raise RuntimeError("a rank failed its first local training step (this rank: %r)" % (failure,))
         if world > 1:
             bucket = model.gradient_bucket()     # the gradients ARE views of one flat buffer: one collective, no copy
             if bucket is not None:
@@ -289,6 +304,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # CPU control group (votes before optional collective sections; a dead peer raises here instead of hanging RCCL)
+        ctl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
 
     from multistgraph_amd import build as mbuild
     from multistgraph_amd import synthetic as syn
@@ -528,7 +545,7 @@ def main():
     if distributed and not args.no_train_step:
         # every rank takes part (the gradient all-reduce is a collective); rank 0 reports
         try:
-            ts = train_step_times(model, batch, w, world=world, device=device)
+            ts = train_step_times(model, batch, w, world=world, device=device, ctl=ctl_group)
         except Exception as exc:   # noqa: BLE001 - the headline line must survive a failure of the optional section
             ts = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0:
