@@ -116,7 +116,12 @@ int mix_transposed(const Bwd& b, const float* src, int rows, int Cc, float* dst,
       a.parts = P.Ks; a.nK = P.Np / 16;
       a.aPartStride = (long)P.Np * P.NpC; a.xPartStride = (long)P.Np * H; a.outPartStride = partStride;
     }
-    hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * rows), (unsigned)a.parts), dim3(256), 0, b.c.s, a);
+    if ((rows & 1) == 0) {   // 32-row x 128-column tiles: 3 % row padding instead of 10 %, 4.9 workgroups per CU (k_mix_n32)
+      a.nRowTiles = (P.N + 31) / 32;
+      hipLaunchKernelGGL(k_mix_n32, dim3((unsigned)(a.nRowTiles * (rows / 2)), (unsigned)a.parts), dim3(256), 0, b.c.s, a);
+    } else {
+      hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * rows), (unsigned)a.parts), dim3(256), 0, b.c.s, a);
+    }
     return launch_ok();
   }
   GemmArgs g = gemm_args(b.c.prep + P.oSt, src + (size_t)P.Np * Cc, dst, P.N, Cc, P.Ks * P.Np);
@@ -735,32 +740,41 @@ int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const f
 // layer's chain: event step[0][l]; the x columns of the layer run on the main stream meanwhile and signal mixed[0][l]).
 // tailOnMain (the LAST layer processed, nothing left for the main stream to overlap with): the second stream keeps the
 // node-adaptive weight gradients and the pools, the other gradients (bwd_layer_other_grads) go to the main stream.
+// Operands of a layer's weight gradients that depend on the FORWARD only: h_{t-1} as one contiguous sequence, z*h, the
+// residual cell's inputs, layer 0's time-major input.  With two streams they are built at the very start of the backward,
+// beside the head and the first chain (the weight-gradient stream idles there), for the two layers whose scratch sets are
+// free then; deeper encoders prepare the remaining layers where they always did, right before the layer's gradients.
+int bwd_prep_operands(Pass& pass, const LayerBufs& L, hipStream_t on) {
+  PASS_LOCALS(pass);
+  LAYER_LOCALS(L);
+  if (l == 0) {
+    hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, on,
+                       c.ws + P.oX0p, tr + R.oX0tm, B, T, Np, P.C0);
+    CHECK_LAUNCH();
+  }
+  float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
+  float* Z2HA = tr + R.oZ2HA[par];
+  if (h0) HIP_OK(hipMemcpyAsync(Hprev, h0, (size_t)slab * sizeof(float), hipMemcpyDeviceToDevice, on));
+  else RETURN_IF(zero_async(Hprev, slab, on));
+  if (T > 1)
+    HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, on));
+  const size_t seqN = (size_t)T * slab;
+  hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, on, tr + R.oZ[l], Hprev, ZH, seqN);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, on, tr + R.oR[l], Hprev, tr + R.oHC[l],
+                     tr + R.oZ2[l], HA, Z2HA, seqN);
+  CHECK_LAUNCH();
+  return MATGCN_OK;
+}
+inline bool prep_hoisted(const Pass& pass, int l) { return pass.twoStreams && l >= pass.b.c.P.L - 2; }
+
 int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   PASS_LOCALS(pass);
   LAYER_LOCALS(L);
   if (twoStreams) HIP_OK(hipStreamWaitEvent(ws, g_wf.step[0][l], 0));
-  const float* Xall;
-  if (l == 0) {
-    float* X0tm = tr + R.oX0tm;
-    hipLaunchKernelGGL(k_x0_time_major, dim3(blocks_for((size_t)T * B * Np * P.C0)), dim3(256), 0, ws,
-                       c.ws + P.oX0p, X0tm, B, T, Np, P.C0);
-    CHECK_LAUNCH();
-    Xall = X0tm;
-  } else {
-    Xall = c.ws + P.oSeq[l - 1];
-  }
-  float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par]; float* HA = tr + R.oHA[par];
-  float* Z2HA = tr + R.oZ2HA[par];
-  if (h0) HIP_OK(hipMemcpyAsync(Hprev, h0, (size_t)slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
-  else RETURN_IF(zero_async(Hprev, slab, ws));
-  if (T > 1)
-    HIP_OK(hipMemcpyAsync(Hprev + slab, seq, (size_t)(T - 1) * slab * sizeof(float), hipMemcpyDeviceToDevice, ws));
-  const size_t seqN = (size_t)T * slab;
-  hipLaunchKernelGGL(k_mul, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oZ[l], Hprev, ZH, seqN);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ha_all, dim3(blocks_for(seqN)), dim3(256), 0, ws, tr + R.oR[l], Hprev, tr + R.oHC[l],
-                     tr + R.oZ2[l], HA, Z2HA, seqN);
-  CHECK_LAUNCH();
+  const float* Xall = l == 0 ? tr + R.oX0tm : c.ws + P.oSeq[l - 1];
+  float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par];
+  if (!prep_hoisted(pass, l)) RETURN_IF(bwd_prep_operands(pass, L, ws));
   if (twoStreams && tailOnMain) {   // the main stream takes the other gradients once these operands exist
     HIP_OK(hipEventRecord(g_wf.xdone[0][l], ws));
     HIP_OK(hipStreamWaitEvent(s, g_wf.xdone[0][l], 0));
@@ -1038,11 +1052,10 @@ int backward_impl(Bwd& b, const float* dOut) {
   q.bx.c.s = q.xs;
   q.chunk = P.T >= 8 ? (P.T + 3) / 4 : P.T;
 
-  RETURN_IF(bwd_clear(q));
-  RETURN_IF(bwd_head(q, dOut));
+  LayerBufs LB[MATGCN_MAX_LAYERS];
   int cur = 0;   // which of the two sequence-gradient buffers holds the gradient of the current layer's output
   for (int l = P.L - 1; l >= 0; --l) {
-    LayerBufs L;
+    LayerBufs& L = LB[l];
     L.l = l; L.C = P.Cl[l]; L.I = L.C + H; L.par = P.L > 1 ? (l & 1) : 0;
     L.seq = b.c.ws + P.oSeq[l];
     L.h0 = b.hasH0 ? tr + R.oH0 + (size_t)l * P.B * P.Np * H : nullptr;
@@ -1057,6 +1070,18 @@ int backward_impl(Bwd& b, const float* dOut) {
     // into this layer's gate block of step t+1 and is back-propagated together with it
     L.mergeAbove = !P.gcnOff && l + 1 < P.L;
     L.narrow = L.C != H;   // layer 0: a handful of input channels
+    if (l > 0) cur ^= 1;
+  }
+  if (q.twoStreams) {   // forward-only operands of the first two layers' weight gradients: now, on the idle second stream
+    HIP_OK(hipEventRecord(g_wf.fork, q.s));
+    HIP_OK(hipStreamWaitEvent(q.ws, g_wf.fork, 0));
+    for (int l = P.L - 1; l >= 0; --l)
+      if (prep_hoisted(q, l)) RETURN_IF(bwd_prep_operands(q, LB[l], q.ws));
+  }
+  RETURN_IF(bwd_clear(q));
+  RETURN_IF(bwd_head(q, dOut));
+  for (int l = P.L - 1; l >= 0; --l) {
+    const LayerBufs& L = LB[l];
     if (q.twoStreams && l + 2 < P.L) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l + 2], 0));   // scratch set is free again
     if (P.gcnOff) {
       RETURN_IF(bwd_dense_layer(q, L));
@@ -1070,7 +1095,6 @@ int backward_impl(Bwd& b, const float* dOut) {
       }
       RETURN_IF(bwd_layer_weights(q, L, l == 0));
     }
-    if (l > 0) cur ^= 1;
   }
   if (q.twoStreams)
     for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l], 0));   // join

@@ -546,6 +546,126 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// 5a'. the same mix with a 32-row x 128-column workgroup tile (the backward's transposed mix)
+// -------------------------------------------------------------------------------------------------
+// The transposed mix has N = 403 output rows: 7 row tiles of 64 are 10 % padding and 7 x 64 x 3 parts = 1344 workgroups
+// are 5.25 per CU (one CU in four runs a sixth round).  32-row tiles cover 416 rows (3 %), and with 128 columns - two
+// batch rows - per workgroup 13 x 32 x 3 = 1248 workgroups are 4.9 per CU.  Each of the 4 waves owns 32 of the 128 columns
+// and all 32 rows: the same 2 x 2 accumulators, K-tile 16, two tiles ahead in registers, rotated LDS rows (16 floats per odd
+// k: the two k rows a 32-lane half reads sit half a bank row apart) and write-through row-store epilogue as k_mix.
+// Needs an even number of column tiles (the launcher falls back to k_mix<2> otherwise).
+__global__ __launch_bounds__(256) void k_mix_n32(MixArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][16 * 32];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
+  const int id = blockIdx.x;
+  const int nPairs = a.nColTiles >> 1;
+  int colPair, rowTile;
+  if ((nPairs & 7) == 0) {
+    const int xcd = id & 7, jj = id >> 3, cpx = nPairs >> 3;
+    rowTile = jj % a.nRowTiles;
+    colPair = xcd * cpx + jj / a.nRowTiles;
+  } else {
+    rowTile = id % a.nRowTiles;
+    colPair = id / a.nRowTiles;
+  }
+  const int row0 = rowTile * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int part = blockIdx.y;
+  // staging: A tile 16 k x 32 rows = 128 float4 (threads t and t + 128 fetch and store the same one: no branch in the
+  // pipeline), B tile 16 k x 128 columns = two float4 per thread (column tiles 2 colPair and 2 colPair + 1)
+  const int akk = (tid & 127) >> 3, asg = tid & 7;
+  const int bkk = tid >> 4, bsg = tid & 15;
+  const float* ap = a.St + (size_t)part * a.aPartStride + (size_t)akk * a.ldS + row0 + asg * 4;
+  const float* bp0 = a.X + (size_t)part * a.xPartStride + (size_t)(2 * colPair) * a.xTileStride + (size_t)bkk * a.ldX + bsg * 4;
+  const float* bp1 = bp0 + a.xTileStride;
+  const int aPos = akk * 32 + ((asg * 4 + 16 * (akk & 1)) & 31);
+  const int bPos0 = bkk * 128 + ((bsg * 4 + 16 * (bkk & 1)) & 127);
+  const int bPos1 = bkk * 128 + ((64 + bsg * 4 + 16 * (bkk & 1)) & 127);
+  const int last = a.nK - 1;
+  auto ldA = [&](int t) { return *reinterpret_cast<const float4*>(ap + (size_t)min(t, last) * 16 * a.ldS); };
+  auto ldB0 = [&](int t) { return *reinterpret_cast<const float4*>(bp0 + (size_t)min(t, last) * 16 * a.ldX); };
+  auto ldB1 = [&](int t) { return *reinterpret_cast<const float4*>(bp1 + (size_t)min(t, last) * 16 * a.ldX); };
+  {
+    const float4 a0 = ldA(0), b0 = ldB0(0), b1 = ldB1(0);
+    *reinterpret_cast<float4*>(&As[0][aPos]) = a0;
+    *reinterpret_cast<float4*>(&Bs[0][bPos0]) = b0;
+    *reinterpret_cast<float4*>(&Bs[0][bPos1]) = b1;
+  }
+  float4 ra0 = ldA(1), rb00 = ldB0(1), rb01 = ldB1(1), ra1 = ldA(2), rb10 = ldB0(2), rb11 = ldB1(2);
+  __syncthreads();
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment of reduction index k = 4 s + kq: its row is rotated by 16 * (k & 1) = 16 * (kq & 1)
+  const int rot = 16 * (kq & 1);
+  const int cA0 = (j + rot) & 31, cA1 = (16 + j + rot) & 31;
+  const int cB0 = (w * 32 + j + rot) & 127, cB1 = (w * 32 + 16 + j + rot) & 127;
+  auto mma = [&](int cur) {
+    const float* A = &As[cur][kq * 32];
+    const float* Bm = &Bs[cur][kq * 128];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float a0 = A[s * 128 + cA0], a1 = A[s * 128 + cA1];
+      const float b0 = Bm[s * 512 + cB0], b1 = Bm[s * 512 + cB1];
+      acc[0][0] = MFMA16(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA16(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA16(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA16(a1, b1, acc[1][1]);
+    }
+  };
+  for (int it = 0; it < a.nK; it += 2) {
+    mma(0);                                               // tile it
+    *reinterpret_cast<float4*>(&As[1][aPos]) = ra0;       // tile it+1 (a clamped copy past the end: unused)
+    *reinterpret_cast<float4*>(&Bs[1][bPos0]) = rb00;
+    *reinterpret_cast<float4*>(&Bs[1][bPos1]) = rb01;
+    ra0 = ldA(it + 3); rb00 = ldB0(it + 3); rb01 = ldB1(it + 3);
+    __syncthreads();
+    if (it + 1 < a.nK) {
+      mma(1);                                             // tile it+1
+      *reinterpret_cast<float4*>(&As[0][aPos]) = ra1;     // tile it+2
+      *reinterpret_cast<float4*>(&Bs[0][bPos0]) = rb10;
+      *reinterpret_cast<float4*>(&Bs[0][bPos1]) = rb11;
+      ra1 = ldA(it + 4); rb10 = ldB0(it + 4); rb11 = ldB1(it + 4);
+      __syncthreads();
+    }
+  }
+  // epilogue as k_mix: the wave's 32 x 32 tile through LDS (Bs is free after the last barrier), 16-byte write-through stores
+  float* stg = &Bs[0][0] + w * 1024;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lrow = p * 16 + 4 * kq + e, lcol = q * 16 + j;
+        stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
+      }
+  const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
+  float* outp = a.out + (size_t)part * a.outPartStride;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+  const int colTile = 2 * colPair + (w >> 1), wc = w & 1;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lrow = u * 8 + (lane >> 3), q = lane & 7;
+    const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+    const int row = row0 + lrow;
+    const int k = row / a.Np, n = row - k * a.Np;
+    if (k < a.Ks && n < a.N) {
+      const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
+      if (wt) {
+        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
+      } else {
+        *reinterpret_cast<float4*>(outp + off) = v;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // 5b. the same graph mix with bf16 OPERANDS (BASELINE config 3's dtype): fp32 accumulation, fp32 inputs and outputs
 // -------------------------------------------------------------------------------------------------
 // Opt-in variant (matgcn_set_mix_precision(1); inference only, never the headline: narrower than the reference's fp32).
