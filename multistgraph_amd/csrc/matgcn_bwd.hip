@@ -227,13 +227,13 @@ StepBlocks chunk_blocks(const Plan& P, const float* base) {
 }
 // all slots of a node in one workgroup (k_wgrad_node); false = shape outside what the kernel covers
 bool node_wgrad_fast(const Bwd& b, const float* U, const StepBlocks& sb, const float* dPre, int O, int I, int iOfs,
-                     float* dWp, int* rc) {
+                     float* dWp, int* rc, float* dBias = nullptr) {
   const Plan& P = b.c.P;
   const int S = b.c.R.S;
   if (S != P.Ks + 1 || S > 5 || S == 3 || S < 2 || P.T > MAX_STEPS || (O != 128 && O != 64)) return false;
   WgradNodeArgs a;
   memset(&a, 0, sizeof(a));
-  a.U = U; a.dPre = dPre; a.dW = dWp + (size_t)iOfs * O;
+  a.U = U; a.dPre = dPre; a.dW = dWp + (size_t)iOfs * O; a.dBias = dBias;
   for (int t = 0; t < P.T; ++t) { a.g[t] = sb.g[t]; a.gNode[t] = sb.gNode[t]; }
   a.T = P.T; a.B = P.B; a.N = P.N; a.Np = P.Np; a.S = S; a.Ks = P.Ks; a.I = I;
   // parts: enough workgroups for a few full rounds of the chip (2 resident per CU at O = 128, 3 at O = 64) without a
@@ -247,7 +247,7 @@ bool node_wgrad_fast(const Bwd& b, const float* U, const StepBlocks& sb, const f
   if (O == 128) {
     if (S == 4) WGN(128, 4, 4);        // 512 threads, 128 registers: two workgroups per compute unit
     else if (S == 5) WGN(128, 5, 2);
-    else if (S == 2) WGN(128, 2, 4);
+    else if (S == 2) WGN(128, 2, 3);
     else return false;
   } else {
     if (S == 4) WGN(64, 4, 3);
@@ -799,7 +799,7 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
     } else {
       sb = uniform_blocks(P, tr + R.oGH[l]);   // the top layer: private blocks [T][N][B][Ks][64]
     }
-    fastH = node_wgrad_fast(bw, Hprev, sb, DPG, 128, I, C, dWpG, &rc);
+    fastH = node_wgrad_fast(bw, Hprev, sb, DPG, 128, I, C, dWpG, &rc, tr + R.oDBias[l][0]);   // + the gate's bias gradient
     RETURN_IF(rc);
   }
   if (fastH) {
@@ -823,7 +823,9 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
     RETURN_IF(node_weight_grad(bw, Hprev, mh, H, DPG, 128, I, C, 0, rowsTB, dWpG));
   }
   // z * h rows of the candidate's AGCN
-  if (!(P.Ks > 0 && node_wgrad_fast(bw, ZH, uniform_blocks(P, tr + R.oGZH[l]), DPU, 64, I, C, dWpU, &rc))) {
+  const bool fastZ = P.Ks > 0 && node_wgrad_fast(bw, ZH, uniform_blocks(P, tr + R.oGZH[l]), DPU, 64, I, C, dWpU, &rc,
+                                                 tr + R.oDBias[l][1]);   // + the candidate's bias gradient
+  if (!fastZ) {
     MixedRows mz = {tr + R.oGZH[l], (long)B * P.Ks * H, H, gStep, (long)P.Ks * H, T, B};
     RETURN_IF(node_weight_grad(bw, ZH, mz, H, DPU, 64, I, C, 0, rowsTB, dWpU));
   }
@@ -864,12 +866,16 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
       t0 += nt;
     }
   }
-  hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
-                     Np, 128, tr + R.oDBias[l][0]);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
-                     64, tr + R.oDBias[l][1]);
-  CHECK_LAUNCH();
+  if (!fastH) {   // (k_wgrad_node summed the columns of the rows it streamed; the GEMM path needs the extra pass)
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 128), 24), dim3(256), 0, ws, DPG, (size_t)rowsTB, N,
+                       Np, 128, tr + R.oDBias[l][0]);
+    CHECK_LAUNCH();
+  }
+  if (!fastZ) {
+    hipLaunchKernelGGL(k_node_colsum, dim3(blocks_for((size_t)N * 64), 24), dim3(256), 0, ws, DPU, (size_t)rowsTB, N, Np,
+                       64, tr + R.oDBias[l][1]);
+    CHECK_LAUNCH();
+  }
   if (!(twoStreams && tailOnMain)) {
     if (twoStreams) HIP_OK(hipStreamWaitEvent(ws, g_wf.mixed[0][l], 0));   // DAx comes from the x columns (main stream)
     RETURN_IF(bwd_layer_other_grads(pass, L, bw, Xall));
