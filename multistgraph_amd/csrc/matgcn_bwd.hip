@@ -280,13 +280,16 @@ int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int C
 }
 
 // nn.Linear weight gradient: dW[o][iOfs + i] = sum_rows dPre[rows][o] * In[rows][i]   (rows = every (t, b, n))
+// (bias / biasDone: the bias gradient = the column sums of dPre falls out of the fast kernel's operand stream; *biasDone
+// says whether this call took it along - the caller runs k_colsum_all otherwise)
 int linear_weight_grad(const Bwd& b, const float* dPre, int O, const float* In, int Cc, long rows, int I, int iOfs,
-                       float* dW) {
+                       float* dW, float* bias = nullptr, bool* biasDone = nullptr) {
   GemmArgs g = gemm_args(dPre, In, dW + iOfs, O, Cc, (int)rows);   // rows < 2^31 is checked by the caller
   g.sAm = 1; g.sAk = O;
   g.sBk = Cc; g.sBn = 1;
   g.sCm = I; g.sCn = 1;
   g.mode = 1; g.split = 256;
+  if (bias && tn_eligible(g)) { g.colsumA = bias; *biasDone = true; }
   return gemm(g, 1, b.c.s, BG_LINEAR);
 }
 
@@ -723,16 +726,21 @@ int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const f
   RETURN_IF(zero_async(gg.weight, 128L * I, xs));
   RETURN_IF(zero_async(gu.weight, 64L * I, xs));
   const long rows = (long)rowsTB * Np;
-  RETURN_IF(linear_weight_grad(bx, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
-  RETURN_IF(linear_weight_grad(bx, DPG2, 128, HA, H, rows, I, C, gg.weight));
-  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
-  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Z2HA, H, rows, I, C, gu.weight));
   RETURN_IF(zero_async(gg.bias, 128, xs));
   RETURN_IF(zero_async(gu.bias, 64, xs));
-  hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
-  CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
-  CHECK_LAUNCH();
+  bool biasG = false, biasU = false;   // the h-column GEMMs (64 input channels: fast kernel) take the bias sums along
+  RETURN_IF(linear_weight_grad(bx, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+  RETURN_IF(linear_weight_grad(bx, DPG2, 128, HA, H, rows, I, C, gg.weight, gg.bias, &biasG));
+  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Z2HA, H, rows, I, C, gu.weight, gu.bias, &biasU));
+  if (!biasG) {   // (the rows of the padding nodes are zero in DPG2 / DPU2: summing them with the operand stream is exact)
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
+    CHECK_LAUNCH();
+  }
+  if (!biasU) {
+    hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPU2, (size_t)rowsTB, N, Np, 64, 64, gu.bias);
+    CHECK_LAUNCH();
+  }
   return MATGCN_OK;
 }
 

@@ -27,6 +27,8 @@ struct GemmArgs {
   long bA1, bA2, bB1, bB2, bC1, bC2;
   float alpha, beta;
   int mode, split;
+  float* colsumA;                // k_bgemm_tn only: [M] += column sums of A over the whole reduction (nn.Linear bias
+                                 // gradients: A = the pre-activation gradients), added by the workgroups of column tile 0
 };
 
 #define BG_LD 80   // LDS row pitch (floats): 80 = 16 mod 32, so k and k + 1 sit half a bank row apart
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void k_bgemm_tn(GemmArgs g) {
   // the fetch stream walks the (k2, k-tile) pairs of this part in order; past the end it re-reads the last tile, zeroed
   int fk2 = tBeg / kTiles, fkt = tBeg - fk2 * kTiles, fetched = tBeg;
   const int lastK2 = (tEnd - 1) / kTiles, lastKt = (tEnd - 1) - lastK2 * kTiles;
+  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](float4& ra, float4& rb) {
     const bool live = fetched < tEnd;
     const int k2 = live ? fk2 : lastK2, kt = live ? fkt : lastKt;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void k_bgemm_tn(GemmArgs g) {
     const bool ok = live && k < g.K;
     ra = make_float4(ok ? va.x : 0.f, ok ? va.y : 0.f, ok ? va.z : 0.f, ok ? va.w : 0.f);
     rb = make_float4(ok ? vb.x : 0.f, ok ? vb.y : 0.f, ok ? vb.z : 0.f, ok ? vb.w : 0.f);
+    asum = make_float4(asum.x + ra.x, asum.y + ra.y, asum.z + ra.z, asum.w + ra.w);   // every row of A passes here once
   };
   f32x4 acc[2][2];
 #pragma unroll
@@ -281,6 +285,16 @@ __global__ __launch_bounds__(256) void k_bgemm_tn(GemmArgs g) {
         *reinterpret_cast<float4*>(&Bs[0][stPos]) = rb1;
         fetch(ra1, rb1);
         __syncthreads();
+      }
+    }
+    if (g.colsumA && blockIdx.x == 0) {   // the 16 threads that hold the same 4 columns (one per k row of a tile) meet in LDS
+      *reinterpret_cast<float4*>(&As[0][kk * 64 + sg * 4]) = asum;
+      __syncthreads();
+      if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += As[0][q * 64 + tid];
+        unsafeAtomicAdd(g.colsumA + m0 + tid, v);
       }
     }
   }
