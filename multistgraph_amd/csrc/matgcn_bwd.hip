@@ -946,8 +946,27 @@ int bwd_pools_layer(Pass& pass, int l, hipStream_t onStream) {
       CHECK_LAUNCH();
       RETURN_IF(zero_async(TmpK, (long)ent.n * N * P.d, s));
       RETURN_IF(zero_async(dgain, 64, s));
+      // entries with distinct pool indices (every cheb_order but 1) go as TWO batched launches - 2 x ent.n dependent 25 us
+      // launches were latency, not work; the batch items are not equally spaced, hence the offset tables
+      bool distinct = ent.n <= 8;
+      for (int e2 = 0; e2 < ent.n && distinct; ++e2)
+        for (int e3 = 0; e3 < e2; ++e3) distinct = distinct && ent.pool[e3] != ent.pool[e2];
+      if (distinct && ent.n > 0) {
+        GemmArgs q = gemm_args(EK, dWp, ag.weights_pool, P.d, (int)IO, N);
+        q.sAm = 1; q.sAk = P.d; q.sBk = (long)S * IO; q.sBn = 1; q.sCm = (long)Kt * IO; q.sCn = 1;
+        GemmArgs e = gemm_args(dWp, ap.weights_pool, TmpK, N, P.d, (int)IO);
+        e.sAm = (long)S * IO; e.sAk = 1; e.sBk = 1; e.sBn = (long)Kt * IO; e.sCm = P.d; e.sCn = 1;
+        e.mode = 1; e.split = 32;
+        q.nOff = e.nOff = ent.n;
+        for (int e2 = 0; e2 < ent.n; ++e2) {
+          q.offA[e2] = (long)e2 * N * P.d; q.offB[e2] = (long)ent.slot[e2] * IO; q.offC[e2] = (long)ent.pool[e2] * IO;
+          e.offA[e2] = (long)ent.slot[e2] * IO; e.offB[e2] = (long)ent.pool[e2] * IO; e.offC[e2] = (long)e2 * N * P.d;
+        }
+        RETURN_IF(gemm(q, ent.n, s, BG_POOL));
+        RETURN_IF(gemm(e, ent.n, s, BG_POOL));
+      }
       bool written[MATGCN_MAX_STACK] = {false};
-      for (int e2 = 0; e2 < ent.n; ++e2) {
+      for (int e2 = 0; e2 < ent.n && !distinct; ++e2) {
         const int k = ent.pool[e2];
         const float* src = dWp + (size_t)ent.slot[e2] * IO;
         GemmArgs q = gemm_args(EK + (size_t)e2 * N * P.d, src, ag.weights_pool + (size_t)k * IO, P.d, (int)IO, N);

@@ -27,6 +27,8 @@ struct GemmArgs {
   long bA1, bA2, bB1, bB2, bC1, bC2;
   float alpha, beta;
   int mode, split;
+  long offA[8], offB[8], offC[8];  // k_bgemm only, nOff > 0: outer batch item b1 < nOff sits at these offsets (floats)
+  int nOff;                        // instead of b1 * bA1 / bB1 / bC1 (batch items that are not equally spaced: the pools)
   float* colsumA;                // k_bgemm_tn only: [M] += column sums of A over the whole reduction (nn.Linear bias
                                  // gradients: A = the pre-activation gradients), added by the workgroups of column tile 0
 };
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
   const int part = z % g.split;
   z /= g.split;
   const int b2 = z % g.nb2, b1 = z / g.nb2;
-  const float* A = g.A + (size_t)b1 * g.bA1 + (size_t)b2 * g.bA2;
-  const float* B = g.B + (size_t)b1 * g.bB1 + (size_t)b2 * g.bB2;
-  float* C = g.C + (size_t)b1 * g.bC1 + (size_t)b2 * g.bC2;
+  const float* A = g.A + (g.nOff ? (size_t)g.offA[b1] : (size_t)b1 * g.bA1) + (size_t)b2 * g.bA2;
+  const float* B = g.B + (g.nOff ? (size_t)g.offB[b1] : (size_t)b1 * g.bB1) + (size_t)b2 * g.bB2;
+  float* C = g.C + (g.nOff ? (size_t)g.offC[b1] : (size_t)b1 * g.bC1) + (size_t)b2 * g.bC2;
   // element of the 64 x 16 A tile (16 x 64 B tile) this thread loads in sweep i: the unit-stride axis runs fastest.
   // When pointer and strides are 16-byte friendly the whole tile is ONE float4 per thread along the unit-stride axis
   // (vecA / vecB, wave-uniform); ragged edges fall back to scalar loads per element of the quad.
