@@ -428,6 +428,9 @@ int bwd_head(Pass& pass, const float* dOut) {
     q.sBk = (long)hT * H; q.sBn = 1; q.bB1 = H;
     q.sCm = H; q.sCn = 1; q.bC1 = slab; q.bC2 = (long)Np * H;
     q.nb2 = B;
+    if (b.dropMask) {   // the dropout mask (B, hT, N, H) of the steps the head saw, applied where the gradient is produced
+      q.scaleC = b.dropMask; q.bS1 = (long)N * H; q.bS2 = (long)hT * N * H; q.sSm = H; q.sSn = 1;
+    }
     RETURN_IF(gemm(q, hT, s, BG_HEAD));
     RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * hT * H, s));
     GemmArgs w = gemm_args(dOutRows, seqTop + (size_t)tOff * slab, g->end_conv_weight, P.CH, H, N);
@@ -437,11 +440,6 @@ int bwd_head(Pass& pass, const float* dOut) {
     w.sCm = (long)hT * H; w.sCn = 1; w.bC1 = H;
     w.mode = 1; w.split = 16;
     RETURN_IF(gemm(w, hT, s, BG_HEAD));
-    if (b.dropMask) {   // mask (B, hT, N, H) on the steps the head saw
-      hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)hT * slab)), dim3(256), 0, s, dSeq + (size_t)tOff * slab,
-                         b.dropMask, dSeq + (size_t)tOff * slab, B, hT, N, Np);
-      CHECK_LAUNCH();
-    }
   }
 
   return MATGCN_OK;

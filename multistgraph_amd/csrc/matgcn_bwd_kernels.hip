@@ -29,6 +29,8 @@ struct GemmArgs {
   int mode, split;
   long offA[8], offB[8], offC[8];  // k_bgemm only, nOff > 0: outer batch item b1 < nOff sits at these offsets (floats)
   int nOff;                        // instead of b1 * bA1 / bB1 / bC1 (batch items that are not equally spaced: the pools)
+  const float* scaleC;           // k_bgemm only: C = scaleC[b1*bS1 + b2*bS2 + m*sSm + n*sSn] * (alpha A.B) (the dropout mask of
+  long sSm, sSn, bS1, bS2;       // the head, applied where the gradient of the head's input is produced)
   float* colsumA;                // k_bgemm_tn only: [M] += column sums of A over the whole reduction (nn.Linear bias
                                  // gradients: A = the pre-activation gradients), added by the workgroups of column tile 0
 };
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
         const int m = m0 + wm * 32 + a * 16 + 4 * kq + e, n = n0 + wn * 32 + b * 16 + j;
         if (m >= g.M || n >= g.N) continue;
         float* dst = C + (size_t)m * g.sCm + (size_t)n * g.sCn;
-        const float v = g.alpha * acc[a][b][e];
+        float v = g.alpha * acc[a][b][e];
+        if (g.scaleC) v *= g.scaleC[(size_t)b1 * g.bS1 + (size_t)b2 * g.bS2 + (size_t)m * g.sSm + (size_t)n * g.sSn];
         if (g.mode == 1) unsafeAtomicAdd(dst, v);
         else *dst = (g.beta != 0.f) ? v + g.beta * *dst : v;
       }
