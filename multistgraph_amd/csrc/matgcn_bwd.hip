@@ -402,7 +402,8 @@ int plain_operands(const Ctx& c, float* tr, hipStream_t s) {
       q.E = c.prm->node_emb; q.wpool = ap.weights_pool; q.wg = c.D->scale_by_g ? ap.weights_g : nullptr;
       q.out = tr + R.oWp[l][part];
       q.d = P.d; q.I = P.Cl[l] + H; q.O = part == 0 ? 128 : 64; q.N = P.N; q.S = R.S; q.map = map;
-      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)R.S * q.I * q.O), (unsigned)P.N), dim3(256), 0, s, q);
+      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)R.S * q.I * q.O), (unsigned)((P.N + PP_NODES - 1) / PP_NODES)),
+                         dim3(256), 0, s, q);
       CHECK_LAUNCH();
     }
   return MATGCN_OK;
