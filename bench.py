@@ -537,7 +537,9 @@ def main():
             bwd_flops = 2.0 * exec_unit * w["batch"] * 24 * w["nodes"]
             ts["backward_executed_tflops"] = bwd_flops / (ts["backward_ms"] * 1e-3) / 1e12
             ts["backward_frac_mfma"] = ts["backward_executed_tflops"] / PEAK_MFMA_F32_TFLOPS
-            ts["backward_flops_note"] = "2 x the forward's executed FLOPs per node-step (%.0f) / backward time" % exec_unit
+            ts["backward_flops_note"] = ("2 x the forward's executed FLOPs per node-step (%.0f) / backward time: an upper "
+                                         "bound of what the backward multiplies (the mixes of the static supports have no "
+                                         "adjacency-gradient GEMM), i.e. a time ratio rather than a utilisation" % exec_unit)
             if cpu_train is not None:
                 ts["cpu_baseline"] = cpu_train
                 ts["gpu_over_cpu"] = ts["node_steps_per_s"] / cpu_train["value"]
