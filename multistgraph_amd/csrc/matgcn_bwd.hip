@@ -743,10 +743,6 @@ int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const f
   return MATGCN_OK;
 }
 
-// Weight gradients of a graph layer, on the second stream when there is one (forked by the caller right after the
-// layer's chain: event step[0][l]; the x columns of the layer run on the main stream meanwhile and signal mixed[0][l]).
-// tailOnMain (the LAST layer processed, nothing left for the main stream to overlap with): the second stream keeps the
-// node-adaptive weight gradients and the pools, the other gradients (bwd_layer_other_grads) go to the main stream.
 // Operands of a layer's weight gradients that depend on the FORWARD only: h_{t-1} as one contiguous sequence, z*h, the
 // residual cell's inputs, layer 0's time-major input.  With two streams they are built at the very start of the backward,
 // beside the head and the first chain (the weight-gradient stream idles there), for the two layers whose scratch sets are
@@ -775,6 +771,10 @@ int bwd_prep_operands(Pass& pass, const LayerBufs& L, hipStream_t on) {
 }
 inline bool prep_hoisted(const Pass& pass, int l) { return pass.twoStreams && l >= pass.b.c.P.L - 2; }
 
+// Weight gradients of a graph layer, on the second stream when there is one (forked by the caller right after the
+// layer's chain: event step[0][l]; the x columns of the layer run on the main stream meanwhile and signal mixed[0][l]).
+// tailOnMain (the LAST layer processed, nothing left for the main stream to overlap with): the second stream keeps the
+// node-adaptive weight gradients and the pools, the other gradients (bwd_layer_other_grads) go to the main stream.
 int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   PASS_LOCALS(pass);
   LAYER_LOCALS(L);
