@@ -160,6 +160,33 @@ def test_backward_matches_oracle_autograd(name, fold, lib_built):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_multi_uni_c2_static", "tiny_od_non_c3", "tiny_multi_uni_c1"])
+def test_backward_one_stream_equals_three_streams(name, lib_built):
+    """matgcn_set_wavefront(0) runs the same kernels on ONE stream (the configuration kernel durations are measured in);
+    the default schedule spreads them over three with events in between: both must give the same gradients (not
+    bit-for-bit: split-K and the bias by-products accumulate with atomics)."""
+    c = Case(name)
+    hp, dev, state = _path(c)
+    rng = np.random.default_rng(c.seed + 3)
+    d_out = torch.from_numpy(rng.standard_normal((c.b, c.out, c.n, 1)).astype(np.float32)).to(dev)
+    x = torch.from_numpy(c.x).to(dev)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
+    res = {}
+    prev = hp.lib.matgcn_set_wavefront(1)
+    try:
+        for mode in (1, 0):
+            hp.lib.matgcn_set_wavefront(mode)
+            hp.forward_train(x, None, h0)
+            res[mode] = {k: v.clone() for k, v in hp.backward(x, d_out, state, None, h0).items()}
+            torch.cuda.synchronize()
+    finally:
+        hp.lib.matgcn_set_wavefront(prev)
+    for k, g in res[1].items():
+        scale = max(float(g.abs().max()), 1e-30)
+        assert float((g - res[0][k]).abs().max()) <= 2e-6 * scale + 1e-9, k
+
+
 # (grad_hid*: rnn_units < 64 runs through the plugin class only - tests/test_hidden_pad.py)
 GRAD_CASES = sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("grad_") and not f.startswith("grad_hid"))
 
