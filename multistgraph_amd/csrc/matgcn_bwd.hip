@@ -341,8 +341,8 @@ struct LayerBufs {
                          *DAu = (L).DAu, *DAx = (L).DAx;                                                            \
   [[maybe_unused]] const float *WpG = (L).WpG, *WpU = (L).WpU, *RG = (L).RG, *RU = (L).RU;                          \
   [[maybe_unused]] const bool mergeAbove = (L).mergeAbove, narrow = (L).narrow;                                     \
-  [[maybe_unused]] float* DH = tr + R.oDH; [[maybe_unused]] float* DHa = tr + R.oDHa;                               \
-  [[maybe_unused]] float* TMP = tr + R.oTmp; [[maybe_unused]] float* MixOut = tr + R.oMixOut
+  [[maybe_unused]] float* DH = tr + R.oDH[par]; [[maybe_unused]] float* DHa = tr + R.oDHa[par];                     \
+  [[maybe_unused]] float* TMP = tr + R.oTmp[par]; [[maybe_unused]] float* MixOut = tr + R.oMixOut[par]
 
 // scratch and outputs start from zero (only what is accumulated into, or what the GEMMs leave untouched)
 int bwd_clear(Pass& pass) {
@@ -361,7 +361,7 @@ int bwd_clear(Pass& pass) {
                        rowsTB, N, Np, H);
     CHECK_LAUNCH();
   }
-  RETURN_IF(zero_async(tr + R.oMixOut, slab * (P.Ks > 1 ? P.Ks : 1), s));
+  for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) RETURN_IF(zero_async(tr + R.oMixOut[q], slab * (P.Ks > 1 ? P.Ks : 1), s));
   RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
   if (Np != N)
     for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
@@ -462,7 +462,7 @@ int bwd_dense_layer(Pass& pass, const LayerBufs& L) {
       a.dseq = dSeqCur + at; a.dcarry = (t == T - 1) ? nullptr : carry[(t + 1) & 1];
       a.hprev = t > 0 ? seq + at - slab : h0;
       a.z2 = tr + R.oZ2[l] + at; a.r2 = tr + R.oR2[l] + at; a.hc2 = tr + R.oHC2[l] + at;
-      a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR;
+      a.dha = carry[t & 1]; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dzh2 = TMP; a.dr = tr + R.oDR[par];
       a.B = B; a.N = N; a.Np = Np; a.S = S;
       const dim3 eg(blocks_for((size_t)slab));
       hipLaunchKernelGGL(k_chain_res_out, dim3(eg.x < 512 ? eg.x : 512), dim3(256), 0, s, a);
@@ -590,16 +590,16 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
     a.dha = DHa; a.dpu2 = DPU2 + at; a.dpg2 = DPG2 + 2 * at; a.dpu = DPU + at; a.dpg = DPG + 2 * at;
     a.dzh2 = TMP; a.dzhA = DAu + at * S; a.dzhMix = P.Ks > 0 ? MixOut : nullptr;
     a.dhA = DAg + at * S; a.dhMix = P.Ks > 0 ? MixOut : nullptr;
-    a.dh = DH; a.dr = tr + R.oDR;
+    a.dh = DH; a.dr = tr + R.oDR[par];
     a.B = B; a.N = N; a.Np = Np; a.S = S;
     a.mixParts = P.Ks > 1 ? P.Ks : 1; a.mixPartStride = slab;     // the transposed mixes arrive split by slot
     const dim3 eg(blocks_for((size_t)slab));
-    if (twoStreams && l + 1 < P.L && (t == T - 1 || (t + 1) % pass.chunk == 0)) {
-      // entering a chunk of the layer above from its top: step t reads the gradient of its output (x columns of the
-      // chunk holding t) and, in its gate block, what rides from step t-1 of the layer above (the chunk holding t-1)
-      const int c0 = t / pass.chunk * pass.chunk;
-      HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][c0], 0));
-      if (c0 > 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][c0 - pass.chunk], 0));
+    if (twoStreams && l + 1 < P.L) {
+      // step t reads the gradient of its output - x columns of the chunk of the layer above that holds t: awaited on
+      // entering the chunk from its top - and, in its gate block, what rides from step t-1 of the layer above: the
+      // chunk below, awaited at the chunk's lowest step
+      if (t == T - 1 || (t + 1) % pass.chunk == 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][t / pass.chunk * pass.chunk], 0));
+      if (t > 0 && t % pass.chunk == 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][t - pass.chunk], 0));
     }
     {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
       FusedResArgs f;
@@ -1112,8 +1112,20 @@ int backward_impl(Bwd& b, const float* dOut) {
   }
   RETURN_IF(bwd_clear(q));
   RETURN_IF(bwd_head(q, dOut));
+  // A wavefront over the layers, as in the forward: step t of layer l needs the x-column gradient of layer l+1 for the
+  // chunk of steps that holds t (and t-1) only - not its whole chain.  Every second layer therefore walks its chain (and
+  // everything else that used to sit on the caller's stream for it) on a library stream, beside the chain of the layer
+  // above; the chunk events of bwd_x_chunk are the only ties between the two.  The chains' scratch exists twice.
+  hipStream_t callerS = q.s;
+  const bool layerWave = q.twoStreams && P.L > 1;
+  if (layerWave) {
+    HIP_OK(hipEventRecord(g_wf.bfork, callerS));                   // scratch cleared, head done
+    HIP_OK(hipStreamWaitEvent(g_wf.bchain, g_wf.bfork, 0));
+  }
   for (int l = P.L - 1; l >= 0; --l) {
     const LayerBufs& L = LB[l];
+    q.s = (layerWave && ((P.L - 1 - l) & 1)) ? g_wf.bchain : callerS;
+    q.b.c.s = q.s;
     if (q.twoStreams && l + 2 < P.L) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l + 2], 0));   // scratch set is free again
     if (P.gcnOff) {
       RETURN_IF(bwd_dense_layer(q, L));
@@ -1127,6 +1139,12 @@ int backward_impl(Bwd& b, const float* dOut) {
       }
       RETURN_IF(bwd_layer_weights(q, L, l == 0));
     }
+  }
+  q.s = callerS;
+  q.b.c.s = callerS;
+  if (layerWave) {
+    HIP_OK(hipEventRecord(g_wf.bjoin, g_wf.bchain));
+    HIP_OK(hipStreamWaitEvent(callerS, g_wf.bjoin, 0));
   }
   if (q.twoStreams)
     for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l], 0));   // join

@@ -173,7 +173,8 @@ struct TrainPlan {
   long oDPU[2], oDPG[2], oDPU2[2], oDPG2[2];   // pre-activation gradients of every step
   long oDSeq[2];                           // gradient of a layer's output sequence (ping-pong)
   long oDAg[2], oDAu[2], oDAx[2];          // [T][B][S][Np][C] gradient of [s | mix(s)] of both AGCNs (h / x columns)
-  long oDH, oDHa, oDR, oTmp, oMixOut;      // [B][Np][64]
+  long oDH[2], oDHa[2], oDR[2], oTmp[2], oMixOut[2];   // [B][Np][64] scratch of a chain (two sets: the chains of two
+                                           // consecutive layers run side by side on two streams)
   long oX0tm, oHprev[2], oZH[2], oHA[2], oZ2HA[2], oDX0;
   long oMixN;                              // [Np][T*B*C0] transposed mix of the narrow layer-0 x columns
   long oDT, oDL, oEK, oFK, oTmpK, oDGain, oDPoolGain, oDOutRows;
@@ -216,8 +217,15 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
     R->oHprev[q] = take(seq); R->oZH[q] = take(seq); R->oHA[q] = take(seq); R->oZ2HA[q] = take(seq);
   }
   R->oDSeq[0] = take(seq); R->oDSeq[1] = take(seq);
-  R->oDH = take(slab); R->oDHa = take(slab); R->oDR = take(slab); R->oTmp = take(slab);
-  R->oMixOut = take(slab * (P.Ks > 1 ? P.Ks : 1));   // one partial result per dense slot (split transposed mix)
+  for (int q = 0; q < 2; ++q) {
+    if (q == 1 && P.L < 2) {
+      R->oDH[1] = R->oDH[0]; R->oDHa[1] = R->oDHa[0]; R->oDR[1] = R->oDR[0]; R->oTmp[1] = R->oTmp[0];
+      R->oMixOut[1] = R->oMixOut[0];
+      break;
+    }
+    R->oDH[q] = take(slab); R->oDHa[q] = take(slab); R->oDR[q] = take(slab); R->oTmp[q] = take(slab);
+    R->oMixOut[q] = take(slab * (P.Ks > 1 ? P.Ks : 1));   // one partial result per dense slot (split transposed mix)
+  }
   R->oX0tm = take((long)P.T * P.B * P.Np * P.C0);
   R->oDX0 = take((long)P.T * P.B * P.Np * P.C0);
   R->oMixN = take((long)P.T * P.B * P.Np * P.C0);
@@ -294,6 +302,8 @@ struct Wavefront {
   hipEvent_t fork, done[MATGCN_MAX_LAYERS];
   hipStream_t aux;                                 // parameter-only side work of forward_train (plain copies for the backward)
   hipStream_t xcol;                                // backward: x-column gradients of a layer, chunk by chunk beside its chain
+  hipStream_t bchain;                              // backward: the chain of every second layer (beside the chain of the layer above)
+  hipEvent_t bfork, bjoin;
   hipEvent_t bready[MATGCN_MAX_LAYERS][MAX_STEPS]; // backward: the chain of layer l has finished step t (a chunk's lowest)
   hipEvent_t bxcol[MATGCN_MAX_LAYERS][MAX_STEPS];  // backward: the x columns of layer l's chunk starting at step t are done
   hipEvent_t auxFork, auxDone;
@@ -329,6 +339,9 @@ int wavefront_ready() {
   HIP_OK(hipEventCreateWithFlags(&g_wf.fork, hipEventDisableTiming));
   HIP_OK(hipStreamCreateWithFlags(&g_wf.aux, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&g_wf.xcol, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&g_wf.bchain, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.bfork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.bjoin, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxFork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxDone, hipEventDisableTiming));
   for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
