@@ -1082,7 +1082,10 @@ int backward_impl(Bwd& b, const float* dOut) {
   q.xs = q.twoStreams ? g_wf.xcol : q.s;
   q.bx = b;
   q.bx.c.s = q.xs;
-  q.chunk = P.T >= 8 ? (P.T + 3) / 4 : P.T;
+#ifndef BX_CHUNKS
+#define BX_CHUNKS 4   // x-column chunks per sequence (lab switch; 2 / 8 / 12 measured: 16.3-16.4 / 16.4 / 16.2 ms against 16.1)
+#endif
+  q.chunk = P.T >= 8 ? (P.T + BX_CHUNKS - 1) / BX_CHUNKS : P.T;
 
   LayerBufs LB[MATGCN_MAX_LAYERS];
   int cur = 0;   // which of the two sequence-gradient buffers holds the gradient of the current layer's output
