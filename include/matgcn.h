@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 9
+#define MATGCN_ABI_VERSION 10
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -150,7 +150,10 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
  * per-batch host copy of data/utils.py:68-72 + batch.py:43-57): series (series_steps, N, F) resident on the
  * device, label_start (B) device int32 - the first target step of each sample -, rel_steps (x_steps) HOST
  * int32 - offset of every window row relative to its label start (multistgraph_amd/windows.py).
- * Row s of sample b is series[label_start[b] + rel_steps[s]]; the caller guarantees they are in range. */
+ * Row s of sample b is series[label_start[b] + rel_steps[s]]; the caller guarantees they are in range
+ * (multistgraph_amd/windows.py::check_label_starts validates a table on the host where it is built).  The kernels
+ * never read outside the series all the same: an out-of-range row is clamped to the first / last row and counted,
+ * see matgcn_series_violations. */
 int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
                           const float* series, int64_t series_steps, const int32_t* label_start,
                           const int32_t* rel_steps, const float* h0, float* out, void* workspace,
@@ -164,6 +167,12 @@ typedef struct matgcn_series {
   const int32_t* label_start; /* (B) device: first target step of every sample */
   const int32_t* rel_steps;   /* (x_steps) HOST: offset of every window row relative to its label start */
 } matgcn_series;
+
+/* Diagnostic for the series entry points (matgcn_forward_series, the matgcn_series source of the training calls,
+ * matgcn_masked_mae{,_grad} with label_start): number of row accesses on the CURRENT device, since the last reset,
+ * whose index label_start[b] + offset fell outside the series and was clamped.  0 = the range contract held.
+ * Synchronises the device (a debugging / validation call, not part of a step); reset != 0 clears the counter. */
+int matgcn_series_violations(int64_t* count, int reset);
 
 /* ---- the pieces (same kernels, exposed for parity tests against the reference's modules) ----
  * temporal-head fusion + channel concat (MultiATGCN.py:365-402): X -> x0 (B, T, N, feat_in) */

@@ -11,7 +11,7 @@ import os
 
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LAYERS = 4
 MAX_HEADS = 8
 MAX_EXT = 16
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "matgcn_forward": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "matgcn_forward_series": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.c_int64, _P,
                                         C.POINTER(C.c_int32), _P, _P, _P, C.c_size_t, _P]),
+    "matgcn_series_violations": (C.c_int, [C.POINTER(C.c_int64), C.c_int]),
     "matgcn_fuse_heads": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, _P, C.c_size_t, _P]),
     "matgcn_agcn_gate_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, C.c_int, _P, _P, _P, _P,
                                        C.c_size_t, _P]),

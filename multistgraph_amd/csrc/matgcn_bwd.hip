@@ -902,7 +902,7 @@ int bwd_fuse_heads(Pass& pass) {
     memset(&a, 0, sizeof(a));
     a.X = b.src ? b.src->series : b.X; a.dx0 = tr + R.oDX0; a.tsg = prm->weight_tsg; a.dgain = dgain;
     if (b.src) {
-      a.labelStart = b.src->label_start;
+      a.labelStart = b.src->label_start; a.seriesSteps = (long)b.src->series_steps;
       for (int s2 = 0; s2 < D->x_steps; ++s2) a.rel[s2] = b.src->rel_steps[s2];
     }
     for (int h = 0; h < D->n_heads; ++h) {
@@ -1169,9 +1169,9 @@ int matgcn_train_bytes(const matgcn_dims* dims, size_t* bytes) {
   return MATGCN_OK;
 }
 
-int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                         const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
-                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
+static int forward_train_impl(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                              const matgcn_series* src, const float* h0, const float* drop_mask, float* out,
+                              void* workspace, size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
   if (!prepared || (!X && !src) || !out || !train) return MATGCN_ERR_NULL;
   if (src) RETURN_IF(check_series(dims, src->series, src->series_steps, src->label_start, src->rel_steps));
   Ctx c;
@@ -1203,7 +1203,7 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   RETURN_IF(plain_operands(c, c.train, aux));
   if (side) HIP_OK(hipEventRecord(g_wf.auxDone, aux));
   float* x0p = c.ws + P.oX0p;
-  if (src) RETURN_IF(fuse_padded(c, src->series, x0p, src->label_start, src->rel_steps));
+  if (src) RETURN_IF(fuse_padded(c, src->series, x0p, src->label_start, src->rel_steps, src->series_steps));
   else RETURN_IF(fuse_padded(c, X, x0p));
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   if (side) HIP_OK(hipStreamWaitEvent(c.s, g_wf.auxDone, 0));
@@ -1219,6 +1219,15 @@ int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, c
   return head_padded(c, seqTop, out);
 }
 
+// a failure between a fork onto the library streams and their join (side stream of the plain operands, the layers'
+// chains) joins them into the caller's stream before the error code is returned (join_library_streams)
+int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                         const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
+                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
+  JOINED(forward_train_impl(dims, params, prepared, X, src, h0, drop_mask, out, workspace, workspace_bytes, train,
+                            train_bytes, stream), stream);
+}
+
 int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
                     const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
                     const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
@@ -1232,7 +1241,7 @@ int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const 
   if (train_bytes < (size_t)b.c.R.floats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   b.X = X; b.dropMask = drop_mask; b.g = grads; b.tr = (float*)train;
   b.hasH0 = h0 != nullptr; b.dH0 = d_h0; b.src = src;
-  return backward_impl(b, d_out);
+  JOINED(backward_impl(b, d_out), stream);
 }
 
 int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* desc, float alpha, float beta,

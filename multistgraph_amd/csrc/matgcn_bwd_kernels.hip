@@ -1303,6 +1303,7 @@ struct FuseBwdArgs {
   const float* X;        // windows (B, xSteps, N, F), or the raw series (steps, N, F) when labelStart != null
   const int* labelStart; // device (B) label starts, or null
   int rel[256];          // series mode: row offsets relative to the label start (MATGCN_MAX_XSTEPS)
+  long seriesSteps;      // series mode: rows of the series (out-of-range rows are clamped and counted)
   const float* dx0;
   const float* tsg;
   const float* ts[8];
@@ -1323,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_fuse_heads_bwd(FuseBwdArgs a) {
     const int t = idx / ((size_t)a.od * a.N);
     float s = 0.f;
     for (int b = 0; b < a.B; ++b) {
-      const size_t xrow = a.labelStart ? (size_t)(a.labelStart[b] + a.rel[a.headBegin[h] + t])
+      const size_t xrow = a.labelStart ? series_row((long)a.labelStart[b] + a.rel[a.headBegin[h] + t], a.seriesSteps)
                                        : (size_t)b * a.xSteps + a.headBegin[h] + t;
       const float xv = a.X[(xrow * a.N + n) * a.F + a.startDim + c];
       s = fmaf(a.dx0[(((size_t)t * a.B + b) * a.Np + n) * a.C0 + c], xv, s);

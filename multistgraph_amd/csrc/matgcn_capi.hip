@@ -310,6 +310,7 @@ struct Wavefront {
   hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
   hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
+  hipEvent_t bail[2 * MATGCN_MAX_LAYERS + 3];      // error exits: one per library stream (join_library_streams)
 };
 // one set per device ordinal: a HIP stream / event belongs to the device that was current when it was created, so a
 // process that drives several GPUs (or the rehearsal runs that put two ranks on one box) must not share them.
@@ -344,6 +345,7 @@ int wavefront_ready() {
   HIP_OK(hipEventCreateWithFlags(&g_wf.bjoin, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxFork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxDone, hipEventDisableTiming));
+  for (int i = 0; i < 2 * MATGCN_MAX_LAYERS + 3; ++i) HIP_OK(hipEventCreateWithFlags(&g_wf.bail[i], hipEventDisableTiming));
   for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
     HIP_OK(hipEventCreateWithFlags(&g_wf.done[l], hipEventDisableTiming));
     for (int t = 0; t < MAX_STEPS; ++t) {
@@ -358,6 +360,32 @@ int wavefront_ready() {
   g_wf.ready = true;
   return MATGCN_OK;
 }
+
+// Error exits of the entry points that fork work onto the library streams (encoder wavefront, forward_train's side
+// stream, the backward's chain / weight-gradient / x-column streams): a failure between fork and join must not return to
+// the caller with those streams still writing into the caller's buffers (workspace, train buffer, gradient bucket - the
+// caller may free or reuse them as soon as ITS stream is idle).  Whatever is in flight on every library stream is joined
+// into the caller's stream; the error code of the failed stage is what the call returns.
+void join_library_streams(hipStream_t caller) {
+  Wavefront& W = g_wf;
+  if (!W.ready) return;
+  hipStream_t all[2 * MATGCN_MAX_LAYERS + 3];
+  int n = 0;
+  for (int l = 1; l < MATGCN_MAX_LAYERS; ++l) { all[n++] = W.chain[l]; all[n++] = W.xpart[l]; }
+  all[n++] = W.aux; all[n++] = W.xcol; all[n++] = W.bchain;
+  for (int i = 0; i < n; ++i) {
+    if (all[i] == caller) continue;
+    if (hipEventRecord(W.bail[i], all[i]) == hipSuccess) (void)hipStreamWaitEvent(caller, W.bail[i], 0);
+  }
+  (void)hipGetLastError();
+}
+// runs `call`, joins the library streams into the caller's stream when it failed
+#define JOINED(call, stream)                                              \
+  do {                                                                    \
+    const int rc_ = (call);                                               \
+    if (rc_ != MATGCN_OK) join_library_streams((hipStream_t)(stream));    \
+    return rc_;                                                           \
+  } while (0)
 
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
@@ -605,7 +633,14 @@ int zero_async(float* p, long floats, hipStream_t s) {
 
 // the encoder over padded buffers: x0p [B][T][Np][C0] -> Seq_{L-1} (time-major [T][B][Np][64]); finalsUser
 // (L,B,N,H) optional.  Layers run as a wavefront over streams (see Wavefront).
+int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* finalsUser);
+// the encoder: its chains fork onto library streams; a failure between fork and join joins them before returning
 int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* finalsUser) {
+  const int rc = encoder_chains(c, x0p, h0User, finalsUser);
+  if (rc != MATGCN_OK) join_library_streams(c.s);
+  return rc;
+}
+int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* finalsUser) {
   const Plan& P = c.P;
   RETURN_IF(node_kernels_ready(P.nodeLds));
   RETURN_IF(wavefront_ready());
@@ -713,14 +748,14 @@ int encoder_padded(const Ctx& c, const float* x0p, const float* h0User, float* f
 }
 
 int fuse_padded(const Ctx& c, const float* X, float* x0p, const int32_t* labelStart = nullptr,
-                const int32_t* relSteps = nullptr) {
+                const int32_t* relSteps = nullptr, int64_t seriesSteps = 0) {
   const Plan& P = c.P;
   const matgcn_dims* D = c.D;
   RETURN_IF(zero_async(x0p, (long)P.B * P.T * P.Np * P.C0, c.s));
   FuseArgs a;
   memset(&a, 0, sizeof(a));
   a.X = X; a.x0 = x0p; a.tsg = c.prm->weight_tsg;
-  a.labelStart = labelStart;
+  a.labelStart = labelStart; a.seriesSteps = (long)seriesSteps;
   if (labelStart)
     for (int s2 = 0; s2 < D->x_steps; ++s2) a.rel[s2] = relSteps[s2];
   for (int h = 0; h < D->n_heads; ++h) { a.ts[h] = c.prm->weight_ts[h]; a.headBegin[h] = D->head_begin[h]; }
@@ -828,6 +863,19 @@ int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* lab
                      out_steps, nodes, out_dim, y_steps, y_feat, y_start, mean, std, null_val, min_s,
                      partials + 2 * (size_t)batch * out_steps, upstream, total, d_pred);
   return launch_ok();
+}
+
+int matgcn_series_violations(int64_t* count, int reset) {
+  if (!count) return MATGCN_ERR_NULL;
+  unsigned long long v = 0;
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_series_violations), sizeof(v)));
+  *count = (int64_t)v;
+  if (reset && v) {
+    v = 0;
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_series_violations), &v, sizeof(v)));
+  }
+  return MATGCN_OK;
 }
 
 int matgcn_set_mix_precision(int mode) {
@@ -1065,7 +1113,7 @@ int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, 
   const Plan& P = c.P;
   float* x0p = c.ws + P.oX0p;
   MixPrecisionScope mixScope(true);
-  RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps));
+  RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps, series_steps));
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
 }

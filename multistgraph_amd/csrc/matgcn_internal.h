@@ -59,6 +59,7 @@ struct FuseArgs {
   const float* X;        // windows (B, xSteps, N, F), or the raw series (steps, N, F) when labelStart != null
   const int* labelStart; // device (B) label starts, or null
   int rel[256];          // series mode: row offsets relative to the label start (MATGCN_MAX_XSTEPS)
+  long seriesSteps;      // series mode: rows of the series (an out-of-range row is clamped and counted, never read)
   float* x0;           // [B][T][Np][C0]
   const float* tsg;
   const float* ts[8];

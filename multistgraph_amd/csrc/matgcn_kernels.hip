@@ -358,6 +358,18 @@ __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ buf, 
 // =================================================================================================
 // x0[b][t][n][c<od]  = sum_h softmax(weight_tsg)[h] * X[b][begin_h + t][n][start+c] * weight_ts[h][t][n][c]
 // x0[b][t][n][od+j]  = X[b][t][n][ext_src[j]]           (time of day / dynamic channels)
+// Series mode: row label_start[b] + offset of the device-resident series.  The caller guarantees the range
+// (include/matgcn.h); a violated contract must not fault the device, so the row is clamped into the series and the
+// violation counted (matgcn_series_violations reads and clears the counter).
+__device__ unsigned long long g_series_violations = 0;
+__device__ __forceinline__ size_t series_row(long row, long steps) {
+  if (row < 0 || row >= steps) {
+    atomicAdd(&g_series_violations, 1ull);
+    row = row < 0 ? 0 : steps - 1;
+  }
+  return (size_t)row;
+}
+
 __global__ __launch_bounds__(256) void k_fuse_heads(FuseArgs a) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t total = (size_t)a.B * a.T * a.N;
@@ -370,7 +382,8 @@ __global__ __launch_bounds__(256) void k_fuse_heads(FuseArgs a) {
   for (int h = 0; h < a.nTs; ++h) gsum += expf(a.tsg[h] - gmax);
   // row `step` of sample b: a window row, or - series mode - the series row at label start + rel[step]
   auto xrow = [&](int step) -> const float* {
-    const size_t r = a.labelStart ? (size_t)(a.labelStart[b] + a.rel[step]) : (size_t)b * a.xSteps + step;
+    const size_t r = a.labelStart ? series_row((long)a.labelStart[b] + a.rel[step], a.seriesSteps)
+                                  : (size_t)b * a.xSteps + step;
     return a.X + (r * a.N + n) * a.F;
   };
   float* dst = a.x0 + (((size_t)b * a.T + t) * a.Np + n) * a.C0;
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(256) void k_mae_partial(const float* __restrict__ p
   __shared__ float sAbs[256], sCnt[256];
   const int b = blockIdx.x / outSteps, o = blockIdx.x - b * outSteps;
   const float* pp = pred + ((size_t)b * outSteps + o) * N * od;
-  const size_t yrow = labelStart ? (size_t)labelStart[b] + o : (size_t)b * ySteps + o;
+  const size_t yrow = labelStart ? series_row((long)labelStart[b] + o, ySteps) : (size_t)b * ySteps + o;
   const float* yp = y + yrow * N * yFeat + yStart;
   const bool nanMask = nullVal != nullVal;
   float sa = 0.f, sc = 0.f;
@@ -921,7 +934,7 @@ __global__ __launch_bounds__(256) void k_mae_grad(const float* __restrict__ pred
   const int n = (idx / od) % N;
   const int o = (idx / ((size_t)od * N)) % outSteps;
   const size_t b = idx / ((size_t)od * N * outSteps);
-  const size_t yrow = labelStart ? (size_t)labelStart[b] + o : b * ySteps + o;
+  const size_t yrow = labelStart ? series_row((long)labelStart[b] + o, ySteps) : b * ySteps + o;
   float l = y[(yrow * N + n) * yFeat + yStart + c] * std + mean;
   const float p = pred[idx] * std + mean;
   if (fabsf(l) < minS) l = 0.f;

@@ -201,9 +201,8 @@ class MultiATGCN(AbstractTrafficStateModel):
             self.node_emb = nn.Parameter(torch.randn(n, embed_dim_cfg))
         self.node_vec1 = nn.Parameter(torch.empty(n, rank))
         self.node_vec2 = nn.Parameter(torch.empty(rank, n))
-        self.spec: PathSpec = spec_from_config(dict(config, rnn_units=hidden_pad.WIDTH), data_feature, n, rank,
-                                               0 if not use_static else len(mats),
-                                               diagonal_mask(self._static_host))
+        self.spec: PathSpec = spec_from_config(config, data_feature, n, rank, 0 if not use_static else len(mats),
+                                               diagonal_mask(self._static_host), hidden=hidden_pad.WIDTH)
         self.output_dim = self.spec.out_dim
         self.feature_final = self.spec.feat_in
         self.len_ts = self.spec.n_ts
@@ -226,6 +225,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         if self.node_specific_off:  # (:350-354)
             self.node_emb = nn.Parameter(torch.ones(n, 1), requires_grad=False)
         self._paths: Dict[int, HotPath] = {}
+        self._valid_label_tables = set()
         self._prepared_key = None
         self.cache_prepared = True
 
@@ -321,13 +321,46 @@ class MultiATGCN(AbstractTrafficStateModel):
         return self.forward(batch)
 
     # ---- the same surface fed from the device-resident raw series (no windows, no labels materialised) ----------
-    def _series_source(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps):
+    def _series_source(self, series: torch.Tensor, label_start, rel_steps):
+        """(series, int32 device label starts, rel_steps), with the range contract of the series entry points checked
+        on the host: every window row and every target row of every sample inside the series (windows.
+        check_label_starts).  A host table (numpy / CPU tensor) is checked before it is uploaded; a device tensor costs
+        one min / max read-back the first time it is seen (tables validated once - e.g. by MTHDatasetResident or
+        windows.epoch_batches - are registered with ``mark_label_starts_valid`` and cost nothing per batch)."""
         from . import windows
         if rel_steps is None:
             rel_steps = windows.window_offsets(self.input_window)
         if not series.is_cuda:
             raise RuntimeError("the series must live on the GPU (HIP path only)")
-        return (series, label_start.to(torch.int32), rel_steps)
+        steps = int(series.shape[0])
+        if not isinstance(label_start, torch.Tensor) or not label_start.is_cuda:
+            host = np.asarray(label_start.cpu() if isinstance(label_start, torch.Tensor) else label_start)
+            windows.check_label_starts(host, rel_steps, self.output_window, steps)
+            return (series, torch.as_tensor(host.astype(np.int32)).to(series.device), rel_steps)
+        ls = label_start.to(torch.int32)
+        base = ls._base if ls._base is not None else ls      # a row of a validated table is a view of it
+        key = (base.data_ptr(), base._version, steps, tuple(int(v) for v in (min(rel_steps), max(rel_steps))))
+        if key not in self._valid_label_tables:
+            lo, hi = (int(v) for v in torch.aminmax(ls))
+            windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
+            if len(self._valid_label_tables) > 64:
+                self._valid_label_tables.clear()
+            if base is not ls:
+                lo, hi = (int(v) for v in torch.aminmax(base))
+                try:
+                    windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
+                    self._valid_label_tables.add(key)      # the whole table holds: its other rows need no check
+                except ValueError:
+                    pass
+            else:
+                self._valid_label_tables.add(key)
+        return (series, ls, rel_steps)
+
+    def mark_label_starts_valid(self, table: torch.Tensor, series_steps: int, rel_steps) -> None:
+        """Register a device table of label starts that has been validated on the host (windows.check_label_starts):
+        batches that are views of it skip the per-call range check."""
+        self._valid_label_tables.add((table.data_ptr(), table._version, int(series_steps),
+                                      tuple(int(v) for v in (min(rel_steps), max(rel_steps)))))
 
     def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
         """forward() without materialised windows: ``series`` (T, N, F) float32 resident on the GPU, ``label_start``
@@ -336,7 +369,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         MTHDataset._generate_input_data + the per-batch host copy (mth_dataset.py:110-160, data/utils.py:68-72,
         batch.py:43-57); trains like forward() when gradients are enabled."""
         src = self._series_source(series, label_start, rel_steps)
-        return self._run(src, int(label_start.shape[0]), series.device)
+        return self._run(src, int(src[1].shape[0]), series.device)
 
     def predict_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
         return self.forward_series(series, label_start, rel_steps)
@@ -345,8 +378,9 @@ class MultiATGCN(AbstractTrafficStateModel):
         """calculate_loss (:422-427) of the batch given by ``label_start``: the prediction from the series-fed forward,
         the targets series[label_start[b] + o] gathered by the loss kernel on the device.  With gradients enabled this is
         the executor's training step (traffic_state_executor.py:411-422) without any host-side window or label."""
-        pred = self.forward_series(series, label_start, rel_steps)
-        ls = label_start.to(torch.int32)
+        src = self._series_source(series, label_start, rel_steps)
+        pred = self._run(src, int(src[1].shape[0]), series.device)
+        ls = src[1]
         affine = self._affine_scaler()
         if affine is not None and series.dtype == torch.float32:
             if pred.requires_grad:
@@ -361,15 +395,19 @@ class MultiATGCN(AbstractTrafficStateModel):
         affine = self._affine_scaler()
         if affine is None:
             raise NotImplementedError("horizon_mae_series needs an affine scaler (StandardScaler / NoneScaler)")
-        pred = self.forward_series(series, label_start, rel_steps)
-        return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1],
-                                 label_start=label_start.to(torch.int32))[1:]
+        src = self._series_source(series, label_start, rel_steps)
+        pred = self._run(src, int(src[1].shape[0]), series.device)
+        return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1], label_start=src[1])[1:]
 
-    def gradient_bucket(self) -> Optional[torch.Tensor]:
-        """The flat fp32 buffer that holds the gradient of every HIP-path parameter after ``loss.backward()`` (their
-        ``.grad`` are views of it), for ONE all-reduce in data-parallel training (sharding.bucket_allreduce_mean_);
-        None when some gradient lives elsewhere (gradients accumulated over several backward calls) - then exchange
-        the ``.grad`` tensors themselves.  The host-side static_initial_* layers are not part of it."""
+    def gradient_exchange(self):
+        """(bucket, leftovers) for the gradient exchange of data-parallel training after ``loss.backward()``:
+        ``bucket`` = the flat fp32 buffer the gradients of the HIP-path parameters are views of (one all-reduce, no
+        copy), or None when some of them live elsewhere (rnn_units < 64: autograd slices the padded gradients back
+        into tensors of their own; gradients accumulated over several backward calls); ``leftovers`` = every other
+        ``.grad`` that is not None - with a bucket these are the host-side ``static_initial_*`` layers of the
+        static-feature path, whose gradients arrive through d_h0 and torch autograd, without one ALL gradients.
+        sharding.allreduce_model_grads_(model) is the entry point that reduces both."""
+        with_grad = [(k, p) for k, p in self.named_parameters() if p.requires_grad and p.grad is not None]
         for hp in self._paths.values():
             b = hp.grad_bucket
             if b is None:
@@ -377,8 +415,16 @@ class MultiATGCN(AbstractTrafficStateModel):
             lo, hi = b.data_ptr(), b.data_ptr() + b.numel() * 4
             mine = [p for k, p in self.named_parameters() if p.requires_grad and not k.startswith("static_initial")]
             if mine and all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in mine):
-                return b
-        return None
+                return b, [p.grad for _, p in with_grad if not lo <= p.grad.data_ptr() < hi]
+        return None, [p.grad for _, p in with_grad]
+
+    def gradient_bucket(self) -> Optional[torch.Tensor]:
+        """The flat fp32 buffer that holds the gradient of EVERY parameter after ``loss.backward()`` (their ``.grad``
+        are views of it) - or None as soon as any gradient lives outside it (static-feature layers, rnn_units < 64,
+        accumulated gradients): reducing the buffer alone would then leave replicas diverging.  Data-parallel loops
+        call sharding.allreduce_model_grads_(model), which handles both cases."""
+        bucket, rest = self.gradient_exchange()
+        return bucket if not rest else None
 
     def _affine_scaler(self):
         """(mean, std) when the scaler de-scales as x*std + mean with scalar parameters (LibCity's StandardScaler /

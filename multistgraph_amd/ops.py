@@ -86,9 +86,11 @@ def diagonal_mask(static_supports) -> int:
 
 
 def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_static: int,
-                     diag_static_mask: int = 0) -> PathSpec:
+                     diag_static_mask: int = 0, hidden: Optional[int] = None) -> PathSpec:
     """Derive the path description from the reference's config / data_feature keys
-    (MultiATGCN.py:224-235, 264-265, 310-332; head windows :371-393)."""
+    (MultiATGCN.py:224-235, 264-265, 310-332; head windows :371-393).  ``config`` only needs ``get`` (LibCity's
+    ConfigParser has no ``keys()``, so it is never copied); ``hidden`` overrides ``rnn_units`` (the padded width the
+    kernels run, hidden_pad.py)."""
     out_window = config.get("output_window", 1)
     start_dim, end_dim = config.get("start_dim", 0), config.get("end_dim", 1)
     od = end_dim - start_dim
@@ -121,7 +123,7 @@ def spec_from_config(config, data_feature, num_nodes: int, adj_rank: int, n_stat
     return PathSpec(
         nodes=num_nodes, out_window=out_window, out_dim=od, start_dim=start_dim,
         in_steps=config.get("input_window", 1), x_steps=lc + lp + lt, x_feat=x_feat,
-        hidden=config.get("rnn_units", 64), layers=config.get("num_layers", 2), feat_in=feat_in,
+        hidden=config.get("rnn_units", 64) if hidden is None else hidden, layers=config.get("num_layers", 2), feat_in=feat_in,
         embed_dim=1 if node_specific_off else config.get("embed_dim_node", 10), adj_rank=adj_rank,
         adpadj=config.get("adpadj", "bidirection"), adjtype=config.get("adjtype", "od"),
         cheb_k=config.get("cheb_order", 2), n_static=n_static, head_begin=tuple(heads),

@@ -85,6 +85,39 @@ def bucket_allreduce_mean_(bucket: torch.Tensor, group=None) -> None:
     bucket /= dist.get_world_size(group)
 
 
+def allreduce_model_grads_(model, group=None, check: bool = True) -> dict:
+    """THE gradient exchange of data-parallel training: in-place mean over ranks of every gradient of ``model`` after
+    ``loss.backward()``.  The flat bucket of the HIP path is reduced as ONE tensor when the model's gradients are
+    views of it (``model.gradient_exchange()``); whatever lives outside it - the host-side ``static_initial_*``
+    layers of the static-feature path, or every gradient when there is no bucket (rnn_units < 64, accumulated
+    gradients) - goes through one flat copy.  Works for any nn.Module (no ``gradient_exchange``: all gradients
+    through the flat copy).
+
+    ``check`` (default): the ranks first agree on the layout with one 3-number all-reduce (MIN and MAX of
+    [has bucket, bucket elements, leftover elements]); a rank whose layout differs would otherwise enter collectives
+    of other sizes than its peers and hang or corrupt them - here every rank raises instead.
+    Returns {"bucket": bool, "bucket_elems": int, "leftover_elems": int}."""
+    if hasattr(model, "gradient_exchange"):
+        bucket, rest = model.gradient_exchange()
+    else:
+        bucket, rest = None, [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    layout = [0 if bucket is None else 1, 0 if bucket is None else bucket.numel(), sum(t.numel() for t in rest)]
+    if check:
+        some = bucket if bucket is not None else (rest[0] if rest else None)
+        dev = some.device if some is not None and dist.get_backend(group) == "nccl" else None
+        lo = torch.tensor(layout, dtype=torch.int64, device=dev)
+        both = torch.stack([lo, -lo])                 # one MIN gives the minimum and (negated) the maximum
+        dist.all_reduce(both, op=dist.ReduceOp.MIN, group=group)
+        if not torch.equal(both[0], -both[1]):
+            raise RuntimeError("allreduce_model_grads_: the ranks disagree on the gradient layout (this rank: bucket=%d, "
+                               "%d bucket elements, %d leftover elements; min over ranks %s, max %s)" % (
+                                   layout[0], layout[1], layout[2], both[0].tolist(), (-both[1]).tolist()))
+    if bucket is not None:
+        bucket_allreduce_mean_(bucket, group=group)
+    flat_allreduce_mean_(rest, group=group)
+    return {"bucket": bucket is not None, "bucket_elems": layout[1], "leftover_elems": layout[2]}
+
+
 def replicas_in_sync(params: Iterable[torch.Tensor], group=None, device=None) -> bool:
     """True when every rank holds bit-identical parameters (checksum all-reduce MIN/MAX).  ``device``: where the
     two checksums travel (a GPU for the nccl/RCCL backend, None = CPU for gloo)."""

@@ -73,17 +73,19 @@ def make_static(n: int, p: int, seed: int) -> np.ndarray:
 
 
 def make_data_feature(n: int, seed: int, city: str = "DC", static_dim: int = 0,
-                      ext_dim: int = 1, scaler=None) -> dict:
-    """The ``data_feature`` dict MTHDataset hands to the model (reference mth_dataset.py:162-176)."""
+                      ext_dim: int = 1, scaler=None, lens=(2, 1, 1)) -> dict:
+    """The ``data_feature`` dict MTHDataset hands to the model (reference mth_dataset.py:162-176).  ``lens`` =
+    (len_closeness, len_period, len_trend) as COUNTS of 24-step blocks, the way the config gives them
+    (config_user.json:11-13; run_model_parameter.py:6-7 sweeps them); the dict carries them in steps (:171-173)."""
     return {
         "num_nodes": n,
         "adj_mx": make_adjacency(n, seed),
         "static": make_static(n, static_dim, seed) if static_dim > 0 else None,
         "coordinate": make_coordinates(n, seed, city),
         "ext_dim": ext_dim,
-        "len_closeness": 48,
-        "len_period": 24,
-        "len_trend": 24,
+        "len_closeness": 24 * int(lens[0]),
+        "len_period": 24 * int(lens[1]),
+        "len_trend": 24 * int(lens[2]),
         "scaler": scaler if scaler is not None else PlainScaler(0.0, 1.0),
         "feature_dim": 1 + ext_dim,
         "output_dim": 1,

@@ -45,6 +45,26 @@ def valid_label_starts(series_steps: int, rel: np.ndarray, input_window: int = 2
     return np.arange(lo, hi + 1, dtype=np.int32) if hi >= lo else np.zeros(0, dtype=np.int32)
 
 
+def check_label_starts(label_starts, rel, output_window: int, series_steps: int) -> None:
+    """The range contract of the series entry points (include/matgcn.h), checked on the host where a table of label
+    starts is built: every window row label_start + rel[s] and every target row label_start + o, o < output_window,
+    must lie inside the series.  Raises ValueError naming the offending extreme.  (The kernels clamp and count a
+    violation instead of faulting, matgcn_series_violations; this is the loud, early form.)"""
+    ls = np.asarray(label_starts).reshape(-1)
+    if ls.size == 0:
+        return
+    rel = np.asarray(rel).reshape(-1)
+    lo, hi = int(ls.min()), int(ls.max())
+    first = lo + (int(rel.min()) if rel.size else 0)
+    if first < 0 or lo < 0:
+        raise ValueError("label start %d reaches row %d: before the series (earliest window offset %d)" % (
+            lo, first, int(rel.min()) if rel.size else 0))
+    last = hi + max(int(output_window) - 1, int(rel.max()) if rel.size else 0)
+    if last >= int(series_steps):
+        raise ValueError("label start %d reaches row %d: the series has %d rows (%d target rows per sample)" % (
+            hi, last, int(series_steps), int(output_window)))
+
+
 def gather_windows(series: np.ndarray, starts: np.ndarray, rel: np.ndarray, output_window: int) -> Tuple[np.ndarray, np.ndarray]:
     """Host restatement of ``_generate_input_data`` for the given label starts: (B, x_steps, N, F) sources and
     (B, output_window, N, F) targets.  Test infrastructure / cross-check only - the product path never builds X."""
@@ -76,10 +96,16 @@ def pad_with_last_sample(indices: np.ndarray, batch_size: int) -> np.ndarray:
 
 
 def epoch_batches(label_starts: np.ndarray, part: np.ndarray, batch_size: int, shuffle: bool = False,
-                  rng: np.random.Generator = None) -> np.ndarray:
+                  rng: np.random.Generator = None, rel: np.ndarray = None, output_window: int = None,
+                  series_steps: int = None) -> np.ndarray:
     """(batches, batch_size) int32 label starts of one epoch over a part of the samples: the part padded with its
     last sample (the reference pads BEFORE the DataLoader shuffles, data/utils.py:53-74), optionally permuted, cut
-    into batches.  A batch on the device is just one row of this table (matgcn_forward_series)."""
+    into batches.  A batch on the device is just one row of this table (matgcn_forward_series).  With ``rel``,
+    ``output_window`` and ``series_steps`` the table is validated against the series range here, once
+    (check_label_starts)."""
+    if series_steps is not None:
+        check_label_starts(np.asarray(label_starts)[np.asarray(part)], rel if rel is not None else np.zeros(0, np.int32),
+                           output_window or 0, series_steps)
     padded = pad_with_last_sample(np.asarray(part), batch_size)
     if shuffle:
         padded = padded[(rng or np.random.default_rng()).permutation(len(padded))]

@@ -32,8 +32,9 @@ from libcity.evaluator.traffic_state_evaluator import TrafficStateEvaluator  # n
 def build_reference(case):
     n = case["nodes"]
     df = syn.make_data_feature(n, case["seed"], case.get("city", "DC"),
-                               static_dim=case.get("static_dim", 0), ext_dim=case["feat"] - 1)
-    cfg = dict(input_window=24, output_window=case["out"], add_time_in_day=True,
+                               static_dim=case.get("static_dim", 0), ext_dim=case["feat"] - 1,
+                               lens=case.get("lens", (2, 1, 1)))
+    cfg = dict(input_window=24, output_window=case["out"], add_time_in_day=case.get("tid", True),
                add_day_in_week=False, load_dynamic=case["feat"] > 2,
                adjtype=case["adjtype"], adpadj=case["adpadj"], cheb_order=case["cheb"],
                embed_dim_node=20, embed_dim_adj=20, rnn_units=64, num_layers=2,
@@ -81,7 +82,8 @@ def run_case(case):
 
 def _run_case(case, model, df, cfg, state):
     n, b = case["nodes"], case["batch"]
-    x, y = syn.make_batch_arrays(b, n, case["out"], case["seed"], feat=case["feat"])
+    x, y = syn.make_batch_arrays(b, n, case["out"], case["seed"], feat=case["feat"],
+                                 x_steps=24 * sum(case.get("lens", (2, 1, 1))))
     xb, yb = torch.from_numpy(x), torch.from_numpy(y)
     out = {}
     out["x_checksum"] = np.float64(x.astype(np.float64).sum())
@@ -195,6 +197,17 @@ CASES.append(dict(name="bm403_out24", nodes=403, batch=4, out=24, feat=2, adjtyp
 CASES.append(dict(name="bm403_out24_bi", nodes=403, batch=2, out=24, feat=2, adjtype="multi",
                   adpadj="bidirection", cheb=2, seed=100, city="BM"))
 
+
+# temporal-head layouts of the reference's first sweep (run_model_parameter.py:6-7: len_closeness / len_period /
+# len_trend), incl. no closeness at all (time of day then comes from the first block there is, MultiATGCN.py:397) and
+# the trend loop that never advances its window (:389-393: three trend heads read the SAME 24 rows); and the
+# add_time_in_day = False corner of the channel ablations (:11-12: one input channel)
+for lens, out, seed in (((1, 0, 0), 3, 10), ((0, 0, 1), 6, 100), ((3, 3, 1), 12, 1000), ((1, 1, 3), 6, 0),
+                        ((0, 1, 1), 6, 10)):
+    CASES.append(dict(name="tiny_heads_%d%d%d" % lens, nodes=21, batch=2, out=out, feat=2, adjtype="multi",
+                      adpadj="unidirection", cheb=2, seed=seed, stages=True, lens=list(lens)))
+CASES.append(dict(name="tiny_notid_c2", nodes=21, batch=2, out=6, feat=1, adjtype="multi", adpadj="unidirection",
+                  cheb=2, seed=10, stages=True, tid=False))
 
 # BASELINE config 5's graph: synthetic 4096 nodes, in 24 -> out 24 (per-GPU share of the batch cut to 2 so that the
 # reference finishes in minutes on CPU); prediction, loss and MAE@k only, static supports as a subsample

@@ -21,7 +21,11 @@ import make_golden as mg  # noqa: E402  (imports the reference)
 
 NAMES = ["tiny_multi_uni_c2", "tiny_multi_bid_c2", "tiny_od_non_c2", "tiny_multi_uni_dyn7", "tiny_multi_uni_c1",
          "tiny_identity_non_c1", "tiny_multi_uni_c2_static", "tiny_cosine_non_c3_static",
-         "hid32_multi_uni_c2", "hid32_multi_uni_c2_static", "hid48_gcnoff"]
+         "hid32_multi_uni_c2", "hid32_multi_uni_c2_static", "hid48_gcnoff",
+         # the headline shapes (B = 4): the padding paths of the backward (403 -> 416 / 448 rows, K = T*B per node)
+         "dc237_out12", "bm403_out24",
+         # head layouts of run_model_parameter.py:6-7 and the one-channel input
+         "tiny_heads_100", "tiny_heads_001", "tiny_heads_331", "tiny_heads_113", "tiny_heads_011", "tiny_notid_c2"]
 SUB = 17
 
 
@@ -29,7 +33,8 @@ def run(case):
     model, df, cfg, state = mg.build_reference(case)
     model.train()
     n, b = case["nodes"], case["batch"]
-    x, y = mg.syn.make_batch_arrays(b, n, case["out"], case["seed"], feat=case["feat"])
+    x, y = mg.syn.make_batch_arrays(b, n, case["out"], case["seed"], feat=case["feat"],
+                                    x_steps=24 * sum(case.get("lens", (2, 1, 1))))
     rng = np.random.default_rng(case["seed"] + 5)
     hid = case.get("flags", {}).get("rnn_units", 64)   # the 64-wide draw is kept for the older fixtures: same bits
     mask = ((rng.random((b, 24, n, hid)) >= 0.1).astype(np.float32) / np.float32(0.9)).astype(np.float32)

@@ -216,13 +216,25 @@ def _fixture_mask(gold):
     return (bits.astype(np.float32) / np.float32(0.9)).astype(np.float32)
 
 
-@pytest.mark.parametrize("name", GRAD_CASES)
-def test_backward_matches_reference_autograd(name, lib_built):
+# the headline shapes also on ONE stream (matgcn_set_wavefront(0)): the schedule kernel durations are measured in
+@pytest.mark.parametrize("name,wavefront", [(n, 1) for n in GRAD_CASES] + [("bm403_out24", 0), ("dc237_out12", 0)])
+def test_backward_matches_reference_autograd(name, wavefront, lib_built):
     """one training-mode step of the reference itself (calculate_loss(batch).backward() with its dropout fed from
-    the stored mask; tests/golden/make_grad_golden.py): prediction and every parameter gradient"""
+    the stored mask; tests/golden/make_grad_golden.py): prediction and every parameter gradient.  grad_dc237_out12 /
+    grad_bm403_out24 are the headline graphs (B = 4): N = 237 / 403 are no multiples of the 16 / 32 / 64-row tiles, so
+    the padding paths of the transposed mix (403 -> 416 rows), of the adjacency-gradient GEMM (403 -> 448) and the
+    per-step tables of the node weight gradients (K = T*B rows per node) meet the reference's own numbers here."""
     c = Case(name)
     gold = np.load(os.path.join(GOLDEN_DIR, "grad_%s.npz" % name))
     hp, dev, state = _path(c)
+    prev = hp.lib.matgcn_set_wavefront(wavefront)
+    try:
+        _backward_vs_fixture(c, gold, hp, dev, state)
+    finally:
+        hp.lib.matgcn_set_wavefront(prev)
+
+
+def _backward_vs_fixture(c, gold, hp, dev, state):
     x = torch.from_numpy(c.x).to(dev)
     mask = torch.from_numpy(_fixture_mask(gold)).to(dev)
     h0 = c.h0()
@@ -244,7 +256,9 @@ def test_backward_matches_reference_autograd(name, lib_built):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["tiny_multi_bid_c2", "tiny_multi_uni_c2", "tiny_multi_uni_c1"])
+@pytest.mark.parametrize("name", ["tiny_multi_bid_c2", "tiny_multi_uni_c2", "tiny_multi_uni_c1", "bm403_out24",
+                                  "dc237_out12", "tiny_heads_100", "tiny_heads_001", "tiny_heads_331", "tiny_heads_113",
+                                  "tiny_heads_011", "tiny_notid_c2"])
 def test_plugin_training_step(name, lib_built, monkeypatch):
     """the plugin surface as TrafficStateExecutor._train_epoch drives it (traffic_state_executor.py:411-422):
     model.train(); loss = model.calculate_loss(batch); loss.backward() -> p.grad of every parameter"""

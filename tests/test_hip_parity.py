@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FULL, TINY, Case, max_norm_err
+from helpers import FULL, TINY, Case, elementwise_excess, max_norm_err
 
 pytestmark = pytest.mark.gpu
 
@@ -171,6 +171,8 @@ def test_forward(name, fold, lib_built):
     got = hp.forward(torch.from_numpy(c.x).to(dev), None if h0 is None else h0.to(dev)).cpu().numpy()
     assert got.shape == c.gold["pred"].shape
     assert max_norm_err(got, c.gold["pred"]) <= E2E_TOL
+    # element-wise: |got - ref| <= 1e-4 |ref| + 1e-6 max|ref| for EVERY prediction
+    assert elementwise_excess(got, c.gold["pred"]) <= 1.0, elementwise_excess(got, c.gold["pred"])
 
 
 BF16_TOL = 5e-3
@@ -247,6 +249,7 @@ def test_config2_dc237_batch64_vs_oracle(lib_built):
                      c.oracle_cfg(), faithful=False).numpy()
     assert got.shape == (64, 12, 237, 1)
     assert max_norm_err(got, want) <= E2E_TOL
+    assert elementwise_excess(got, want) <= 1.0, elementwise_excess(got, want)
 
 
 def test_linearity_of_graph_mix(lib_built):
@@ -336,6 +339,7 @@ def test_forward_synth4096(lib_built):
     got = hp.forward(torch.from_numpy(c.x).to(dev))
     assert got.shape == c.gold["pred"].shape
     assert max_norm_err(got.cpu().numpy(), c.gold["pred"]) <= E2E_TOL
+    assert elementwise_excess(got.cpu().numpy(), c.gold["pred"]) <= 1.0, elementwise_excess(got.cpu().numpy(), c.gold["pred"])
     res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0, null_val=0.0).cpu().numpy()
     assert abs(res[0] - float(c.gold["loss"])) <= 1e-4 * abs(float(c.gold["loss"]))
     res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0).cpu().numpy()

@@ -68,6 +68,47 @@ def test_spec_from_config_heads_and_channels():
     assert spec_from_config(cfg, c.data_feature, c.n, 20, 1).k_total == 3
 
 
+class ConfigParserLike:
+    """The surface of LibCity's ConfigParser (libcity/config/config_parser.py:134-151): get / [] / []= / in / iter over
+    keys - and NO keys(), so dict(config) or {**config} raise."""
+
+    def __init__(self, d):
+        self.config = dict(d)
+
+    def get(self, key, default=None):
+        return self.config.get(key, default)
+
+    def __getitem__(self, key):
+        if key in self.config:
+            return self.config[key]
+        raise KeyError("{} is not in the config".format(key))
+
+    def __setitem__(self, key, value):
+        self.config[key] = value
+
+    def __contains__(self, key):
+        return key in self.config
+
+    def __iter__(self):
+        return self.config.__iter__()
+
+
+@pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "hid32_multi_uni_c2", "tiny_multi_uni_c2_static", "abl_nodeoff"])
+def test_model_builds_from_a_config_parser_like_object(name):
+    """the pipeline hands the constructor a ConfigParser, not a dict (pipeline.py:30,52): the constructor must only use
+    get / [] / []= (and it writes num_nodes back, MultiATGCN.py:233)"""
+    from multistgraph_amd.model import MultiATGCN
+    c = Case(name)
+    cfg = ConfigParserLike(c.config())
+    with pytest.raises((TypeError, ValueError)):
+        dict(cfg, rnn_units=64)       # what a copy of the config would do
+    m = MultiATGCN(cfg, c.data_feature)
+    assert cfg["num_nodes"] == c.n
+    ref = MultiATGCN(c.config(), c.data_feature)
+    assert m.spec == ref.spec and m.spec.hidden == 64
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in ref.named_parameters()]
+
+
 def test_unsupported_options_fail_loudly():
     from multistgraph_amd import synthetic as syn
     from multistgraph_amd.model import MultiATGCN
@@ -85,7 +126,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym)
-    assert lib.matgcn_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.matgcn_abi_version() == _lib.ABI_VERSION == 10
     assert lib.matgcn_error_string(-3) == b"configuration not supported by this build"
 
 

@@ -89,3 +89,95 @@ def test_two_rank_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+# ---- the one data-parallel entry point: sharding.allreduce_model_grads_(model) ------------------------------------------
+def _fake_backward(model, rank, with_bucket):
+    """What loss.backward() leaves behind on the HIP path, imitated on the CPU: the gradients of the HIP-path
+    parameters as views of one flat buffer (HotPath.grad_bucket), the host-side static_initial_* layers' gradients as
+    tensors of their own (they arrive through d_h0 and torch autograd); without a bucket every gradient is its own
+    tensor (rnn_units < 64: autograd slices the padded gradients back).  Values depend on the rank."""
+    import types
+    named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+    hip = [(k, p) for k, p in named if not k.startswith("static_initial")]
+    gen = torch.Generator().manual_seed(100 + rank)
+    if with_bucket:
+        offs, total = {}, 0
+        for k, p in hip:
+            offs[k] = total
+            total += (p.numel() + 63) // 64 * 64
+        bucket = torch.zeros(total)
+        for k, p in hip:
+            view = bucket[offs[k]:offs[k] + p.numel()].view(p.shape)
+            view.copy_(torch.randn(p.shape, generator=gen))
+            p.grad = view
+        model._paths = {2: types.SimpleNamespace(grad_bucket=bucket)}
+    else:
+        for k, p in hip:
+            p.grad = torch.randn(p.shape, generator=gen)
+        model._paths = {}
+    for k, p in named:
+        if k.startswith("static_initial_gru"):      # static_initial_node is never used by forward: no gradient
+            p.grad = torch.randn(p.shape, generator=gen)
+    return {k: p.grad.clone() for k, p in named if p.grad is not None}
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import Case
+    from multistgraph_amd.model import MultiATGCN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for name, with_bucket in (("tiny_multi_uni_c2_static", True), ("hid32_multi_uni_c2", False),
+                                  ("hid32_multi_uni_c2_static", False), ("tiny_multi_uni_c2", True)):
+            c = Case(name)
+            torch.manual_seed(5)                                    # same initial weights on every rank
+            model = MultiATGCN(c.config(), c.data_feature)
+            mine = _fake_backward(model, rank, with_bucket)
+            every = [_fake_backward(MultiATGCN(c.config(), c.data_feature), r, False) for r in range(world)]
+            bucket, rest = model.gradient_exchange()
+            assert (bucket is not None) == with_bucket
+            if c.static_dim > 0:                                    # the pitfall of round 2: these live OUTSIDE the bucket
+                assert rest and model.gradient_bucket() is None
+            elif with_bucket:
+                assert not rest and model.gradient_bucket() is bucket
+            info = sh.allreduce_model_grads_(model)
+            assert info["bucket"] == with_bucket
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    assert k.startswith("static_initial_node") or not p.requires_grad
+                    continue
+                want = sum(e[k] for e in every) / world
+                assert torch.allclose(p.grad, want, atol=1e-6), k
+                assert not torch.equal(p.grad, mine[k]) or float(mine[k].abs().max()) == 0.0
+            opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1)
+            opt.step()
+            assert sh.replicas_in_sync(model.parameters()), name   # replicas stay in sync after the step
+        # ranks that disagree on the layout raise together instead of entering collectives of different sizes
+        c = Case("tiny_multi_uni_c2")
+        torch.manual_seed(5)
+        model = MultiATGCN(c.config(), c.data_feature)
+        _fake_backward(model, rank, with_bucket=(rank == 0))
+        with pytest.raises(RuntimeError, match="disagree"):
+            sh.allreduce_model_grads_(model)
+        # any nn.Module works (no gradient_exchange): all gradients through the flat copy
+        lin = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            lin.weight.fill_(1.0); lin.bias.fill_(0.0)
+        lin(torch.full((1, 3), float(rank + 1))).sum().backward()
+        sh.allreduce_model_grads_(lin)
+        assert torch.allclose(lin.weight.grad, torch.full((2, 3), (world + 1) / 2))
+        open(os.path.join(out_dir, "dp_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_model_grads_two_rank_gloo(tmp_path):
+    """static-feature model (bucket + leftovers), rnn_units = 32 (no bucket), both, and the plain model (bucket only):
+    every gradient becomes the mean over ranks and the replicas stay bit-identical after an optimizer step"""
+    world = 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("dp_ok%d" % r)).exists() for r in range(world))
