@@ -232,6 +232,42 @@ int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* lab
                            float null_val, float min_s, const float* partials, const float* upstream, float* d_pred,
                            void* stream);
 
+/* ---- the evaluator's metric table on the device ------------------------------------
+ * TrafficStateEvaluator.collect (libcity/evaluator/traffic_state_evaluator.py:34-121: ten metrics per horizon, modes
+ * "single" and "average") and the group-std re-transform table of TrafficStateExecutor.evaluate
+ * (libcity/executor/traffic_state_executor.py:293-322) without copying predictions to the host: one pass over
+ * prediction and label reduces, per horizon, the MATGCN_METRIC_SUMS sums every metric is a ratio of (fp64), and
+ * matgcn_metric_table turns (accumulated) sums into the table.
+ *   l = y, p = pred;  first affine x*std + mean (scalar, or one pair per node: per_node) - the scaler's
+ *   inverse_transform (:268-273);  second affine per node - prediction_t = prediction * All_std + All_m (:307-308);
+ *   p := clamp_min where p < clamp_min (:312);  elements with l <= truth_min are left out (:316-317);
+ *   l := 0 where |l| < min_s (loss.py:18, 53, 71; min_s < 0: off - the *_np functions of the re-transform do not).
+ * sums per horizon: 0 elements, 1 non-NaN labels, 2 sum|p-l|, 3 sum (p-l)^2, 4 sum |(p-l)/l| (NaN terms -> 0, as
+ * loss.py does) over those, 5 labels != 0, 6-8 the same three over those, 9 sum l, 10 sum l^2, 11 sum p, 12 sum p^2,
+ * 13 sum (l-p).  Geometry arguments as matgcn_masked_mae (label_start != NULL: y is the raw series).
+ * partials: caller-owned scratch of batch*out_steps*MATGCN_METRIC_SUMS doubles; sums: out_steps*MATGCN_METRIC_SUMS
+ * doubles, overwritten, or added to when accumulate != 0 (several batches = one collect() over their concatenation,
+ * which is how the executor evaluates, :289).  Fixed summation order: run-to-run identical. */
+#define MATGCN_METRIC_SUMS 14
+#define MATGCN_METRICS 10 /* MAE, MAPE, MSE, RMSE, masked_MAE, masked_MAPE, masked_MSE, masked_RMSE, R2, EVAR */
+typedef struct matgcn_metric_scale {
+  const float* mean;   /* device: 1 value, or N with per_node; NULL (with std) = identity */
+  const float* std;
+  int32_t per_node;
+  const float* mean2;  /* device (N) or NULL: second, per-node affine (group-std re-transform) */
+  const float* std2;
+  float clamp_min;     /* NaN: off */
+  float truth_min;     /* NaN: off */
+  float min_s;         /* < 0: off */
+} matgcn_metric_scale;
+int matgcn_metric_sums(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps, int nodes,
+                       int out_dim, int y_steps, int y_feat, int y_start, const matgcn_metric_scale* scale,
+                       double* partials, double* sums, int accumulate, void* stream);
+/* table (2, out_steps, MATGCN_METRICS) doubles, device: [0] "single" mode (horizon o alone), [1] "average" mode
+ * (horizons 0..o), metric order as MATGCN_METRICS above (= TrafficStateEvaluator.json).  swap_r2 != 0: R2 / EVAR with
+ * prediction and truth exchanged, the way traffic_state_executor.py:318-319 calls sklearn. */
+int matgcn_metric_table(const double* sums, int out_steps, int swap_r2, double* table, void* stream);
+
 /* ---- training step: forward that keeps activations + backward -----------
  * Replaces torch autograd through MultiATGCN.forward as driven by TrafficStateExecutor._train_epoch
  * (libcity/executor/traffic_state_executor.py:411-422: loss = calculate_loss(batch); loss.backward()).

@@ -63,6 +63,15 @@ class Params(C.Structure):
     ]
 
 
+class MetricScale(C.Structure):
+    """matgcn_metric_scale"""
+    _fields_ = [("mean", C.c_void_p), ("std", C.c_void_p), ("per_node", C.c_int32), ("mean2", C.c_void_p),
+                ("std2", C.c_void_p), ("clamp_min", C.c_float), ("truth_min", C.c_float), ("min_s", C.c_float)]
+
+
+METRIC_SUMS = 14
+METRICS = ("MAE", "MAPE", "MSE", "RMSE", "masked_MAE", "masked_MAPE", "masked_MSE", "masked_RMSE", "R2", "EVAR")
+
 # every symbol include/matgcn.h declares, with its argument types
 _P = C.c_void_p
 _SIGNATURES = {
@@ -91,6 +100,9 @@ _SIGNATURES = {
                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "matgcn_masked_mae_grad": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "matgcn_metric_sums": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(MetricScale), _P, _P, C.c_int, _P]),
+    "matgcn_metric_table": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "matgcn_train_bytes": (C.c_int, [C.POINTER(Dims), C.POINTER(C.c_size_t)]),
     "matgcn_forward_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), _P, _P, C.POINTER(Series), _P, _P, _P, _P,
                                        C.c_size_t, _P, C.c_size_t, _P]),

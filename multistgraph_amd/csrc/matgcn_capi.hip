@@ -865,6 +865,36 @@ int matgcn_masked_mae_grad(const float* pred, const float* y, const int32_t* lab
   return launch_ok();
 }
 
+int matgcn_metric_sums(const float* pred, const float* y, const int32_t* label_start, int batch, int out_steps, int nodes,
+                       int out_dim, int y_steps, int y_feat, int y_start, const matgcn_metric_scale* scale,
+                       double* partials, double* sums, int accumulate, void* stream) {
+  if (!pred || !y || !scale || !partials || !sums) return MATGCN_ERR_NULL;
+  if (batch < 1 || out_steps < 1 || out_steps > 64 || nodes < 1 || out_dim < 1 || y_steps < out_steps ||
+      y_start < 0 || y_start + out_dim > y_feat)
+    return MATGCN_ERR_BAD_ARG;
+  if ((scale->mean == nullptr) != (scale->std == nullptr) || (scale->mean2 == nullptr) != (scale->std2 == nullptr))
+    return MATGCN_ERR_BAD_ARG;
+  MetricArgs a;
+  a.pred = pred; a.y = y; a.labelStart = label_start;
+  a.mean = scale->mean; a.std = scale->std; a.mean2 = scale->mean2; a.std2 = scale->std2; a.perNode = scale->per_node;
+  a.clampMin = scale->clamp_min; a.truthMin = scale->truth_min; a.minS = scale->min_s;
+  a.outSteps = out_steps; a.N = nodes; a.od = out_dim; a.ySteps = y_steps; a.yFeat = y_feat; a.yStart = y_start;
+  a.partials = partials;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_metric_partial, dim3((unsigned)(batch * out_steps)), dim3(256), 0, s, a);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_metric_accumulate, dim3((unsigned)out_steps), dim3(64), 0, s, partials, batch, out_steps,
+                     accumulate, sums);
+  return launch_ok();
+}
+
+int matgcn_metric_table(const double* sums, int out_steps, int swap_r2, double* table, void* stream) {
+  if (!sums || !table) return MATGCN_ERR_NULL;
+  if (out_steps < 1 || out_steps > 64) return MATGCN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_metric_table, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out_steps, swap_r2, table);
+  return launch_ok();
+}
+
 int matgcn_series_violations(int64_t* count, int reset) {
   if (!count) return MATGCN_ERR_NULL;
   unsigned long long v = 0;

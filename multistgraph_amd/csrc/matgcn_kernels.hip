@@ -920,6 +920,111 @@ __global__ __launch_bounds__(64) void k_mae_final(const float* __restrict__ part
   }
 }
 
+// ---- the evaluator's metric table (traffic_state_evaluator.py:46-121; group-std re-transform of
+// traffic_state_executor.py:293-322) ---------------------------------------------------------------------------------
+// One pass over prediction and label gives, per horizon, the MATGCN_METRIC_SUMS sums every metric of the table is a
+// ratio of; they are accumulated in fp64 (R2 / EVAR subtract squares of means).  Element-wise arithmetic is fp32, like
+// the reference's tensors.  stage 1: one workgroup per (b, horizon) -> partials[b][o][.]; stage 2 adds the batch up
+// in a fixed order (run-to-run identical) and, on request, onto the running sums of earlier batches.
+struct MetricArgs {
+  const float* pred;     // (B, out, N, od)
+  const float* y;        // (B, ySteps, N, yFeat) windows, or the raw series (ySteps, N, yFeat) when labelStart != null
+  const int* labelStart;
+  const float* mean; const float* std;     // first affine x*std + mean: one value, or N values (perNode); null = identity
+  const float* mean2; const float* std2;   // second affine, per node (the group-std re-transform), or null
+  int perNode;
+  float clampMin;        // prediction below -> clampMin (NaN: off)
+  float truthMin;        // only elements whose label exceeds it take part (NaN: off)
+  float minS;            // |label| < minS -> 0 (loss.py:18; < 0: off)
+  int outSteps, N, od, ySteps, yFeat, yStart;
+  double* partials;      // [B*out][MATGCN_METRIC_SUMS]
+};
+constexpr int METRIC_SUMS = 14;
+// sums: 0 elements, 1 non-NaN labels, 2 |d|, 3 d^2, 4 |d/l| (over 1), 5 labels != 0, 6-8 the same three over 5,
+//       9 l, 10 l^2, 11 p, 12 p^2, 13 l-p
+__global__ __launch_bounds__(256) void k_metric_partial(MetricArgs a) {
+  __shared__ double red[4][METRIC_SUMS];
+  const int b = blockIdx.x / a.outSteps, o = blockIdx.x - b * a.outSteps;
+  const float* pp = a.pred + ((size_t)b * a.outSteps + o) * a.N * a.od;
+  const size_t yrow = a.labelStart ? series_row((long)a.labelStart[b] + o, a.ySteps) : (size_t)b * a.ySteps + o;
+  const float* yp = a.y + yrow * a.N * a.yFeat + a.yStart;
+  double s[METRIC_SUMS];
+#pragma unroll
+  for (int k = 0; k < METRIC_SUMS; ++k) s[k] = 0.0;
+  const bool clamp = a.clampMin == a.clampMin, pick = a.truthMin == a.truthMin;
+  for (int idx = threadIdx.x; idx < a.N * a.od; idx += 256) {
+    const int n = idx / a.od, c = idx - n * a.od;
+    float l = yp[(size_t)n * a.yFeat + c], p = pp[idx];
+    if (a.std) { const float sd = a.std[a.perNode ? n : 0], mu = a.mean[a.perNode ? n : 0]; l = l * sd + mu; p = p * sd + mu; }
+    if (a.std2) { l = l * a.std2[n] + a.mean2[n]; p = p * a.std2[n] + a.mean2[n]; }
+    if (clamp && p < a.clampMin) p = a.clampMin;
+    if (pick && !(l > a.truthMin)) continue;
+    if (a.minS >= 0.f && fabsf(l) < a.minS) l = 0.f;
+    const float d = p - l, ad = fabsf(d), sq = d * d, ap = fabsf(d / l);
+    const bool valid = l == l, nz = l != 0.f;          // NaN != 0 holds, as in labels.ne(0)
+    s[0] += 1.0;
+    if (valid) { s[1] += 1.0; s[2] += ad == ad ? ad : 0.f; s[3] += sq == sq ? sq : 0.f; s[4] += ap == ap ? ap : 0.f; }
+    if (nz) { s[5] += 1.0; s[6] += ad == ad ? ad : 0.f; s[7] += sq == sq ? sq : 0.f; s[8] += ap == ap ? ap : 0.f; }
+    const double ld = l, pd = p;
+    s[9] += ld; s[10] += ld * ld; s[11] += pd; s[12] += pd * pd; s[13] += ld - pd;
+  }
+#pragma unroll
+  for (int k = 0; k < METRIC_SUMS; ++k) {
+    double v = s[k];
+    for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_down(v, sh, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < METRIC_SUMS)
+    a.partials[(size_t)blockIdx.x * METRIC_SUMS + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// stage 2: block o, thread k: sums[o][k] (+)= sum_b partials[b][o][k]
+__global__ __launch_bounds__(64) void k_metric_accumulate(const double* __restrict__ partials, int B, int outSteps,
+                                                          int accumulate, double* __restrict__ sums) {
+  const int o = blockIdx.x, k = threadIdx.x;
+  if (k >= METRIC_SUMS) return;
+  double v = 0.0;
+  for (int b = 0; b < B; ++b) v += partials[((size_t)b * outSteps + o) * METRIC_SUMS + k];
+  sums[o * METRIC_SUMS + k] = (accumulate ? sums[o * METRIC_SUMS + k] : 0.0) + v;
+}
+
+// table[mode][o][m]: mode 0 "single" = horizon o alone, mode 1 "average" = horizons 0..o (traffic_state_evaluator.py:
+// 46-121); m: MAE, MAPE, MSE, RMSE, masked_MAE, masked_MAPE, masked_MSE, masked_RMSE, R2, EVAR (the order of
+// TrafficStateEvaluator.json).  swap: R2 / EVAR with prediction and truth exchanged, as traffic_state_executor.py:
+// 318-319 hands them to sklearn.
+__global__ __launch_bounds__(64) void k_metric_table(const double* __restrict__ sums, int outSteps, int swap,
+                                                     double* __restrict__ table) {
+  const int o = threadIdx.x;
+  if (o >= outSteps) return;
+  for (int mode = 0; mode < 2; ++mode) {
+    double s[METRIC_SUMS];
+    for (int k = 0; k < METRIC_SUMS; ++k) s[k] = 0.0;
+    for (int q = mode ? 0 : o; q <= o; ++q)
+      for (int k = 0; k < METRIC_SUMS; ++k) s[k] += sums[q * METRIC_SUMS + k];
+    double* t = table + ((size_t)mode * outSteps + o) * 10;
+    const double n = s[0];
+    // mask / mean(mask) then mean: sum over the kept elements / their count; nothing kept -> nan -> 0 (loss.py:24-27)
+    t[0] = s[1] > 0 ? s[2] / s[1] : 0.0;
+    t[1] = s[1] > 0 ? s[4] / s[1] : 0.0;
+    t[2] = s[1] > 0 ? s[3] / s[1] : 0.0;
+    t[3] = sqrt(t[2]);
+    t[4] = s[5] > 0 ? s[6] / s[5] : 0.0;
+    t[5] = s[5] > 0 ? s[8] / s[5] : 0.0;
+    t[6] = s[5] > 0 ? s[7] / s[5] : 0.0;
+    t[7] = sqrt(t[6]);
+    // sklearn r2_score(y_true, y_pred) = 1 - sum (t-p)^2 / sum (t - mean t)^2, explained_variance_score = 1 - Var(t-p)/Var(t)
+    // (the residual sum leaves NaN labels out; sklearn refuses such input anyway)
+    const double s1 = swap ? s[11] : s[9], s2 = swap ? s[12] : s[10];
+    const double ssTot = n > 0 ? s2 - s1 * s1 / n : 0.0, res = s[3];
+    const double varD = n > 0 ? res / n - (s[13] / n) * (s[13] / n) : 0.0;
+    const double varT = n > 0 ? ssTot / n : 0.0;
+    t[8] = ssTot != 0.0 ? 1.0 - res / ssTot : (res == 0.0 ? 1.0 : 0.0);
+    t[9] = varT != 0.0 ? 1.0 - varD / varT : (varD == 0.0 ? 1.0 : 0.0);
+  }
+}
+
 // gradient of result[0] w.r.t. pred: upstream * std * sign(p - l) * mask / sum(mask)   (torch: d|x| = sign(x), 0 at 0;
 // terms the forward replaced by 0 - NaN differences - get no gradient)
 __global__ __launch_bounds__(256) void k_mae_grad(const float* __restrict__ pred, const float* __restrict__ y,

@@ -103,6 +103,15 @@ class _EncoderParams(nn.Module):
                 self.res_cells.append(_DenseCellParams(cin, hidden))
 
 
+def _is_series_batch(batch) -> bool:
+    """a batch of the resident-series loader (multistgraph_amd.dataset.ResidentBatch): carries the device-resident raw
+    series and B label starts instead of materialised windows"""
+    try:
+        return "label_start" in batch and "series" in batch
+    except TypeError:
+        return False
+
+
 class _TrainStep(torch.autograd.Function):
     """autograd node of one training-mode forward: matgcn_forward_train / matgcn_backward.
     The parameters ride along as inputs so that autograd routes their gradients; X gets none (the reference
@@ -398,6 +407,23 @@ class MultiATGCN(AbstractTrafficStateModel):
         src = self._series_source(series, label_start, rel_steps)
         pred = self._run(src, int(src[1].shape[0]), series.device)
         return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1], label_start=src[1])[1:]
+
+    def collect_metrics(self, evaluator, batch):
+        """One test batch of TrafficStateExecutor.evaluate (traffic_state_executor.py:264-273, 289) without leaving the
+        GPU: predict, de-scale prediction and label with the scaler's affine inside the metric kernel, and reduce into
+        ``evaluator`` (multistgraph_amd.evaluator.DeviceEvaluator).  ``batch`` is a window batch (``X``, ``y``) or a
+        resident-series batch (``series``, ``label_start``: MTHDatasetResident).  Returns the prediction (scaled)."""
+        affine = self._affine_scaler()
+        if affine is None:
+            raise NotImplementedError("collect_metrics needs an affine scaler (StandardScaler / NoneScaler)")
+        if _is_series_batch(batch):
+            src = self._series_source(batch["series"], batch["label_start"], batch.get("rel_steps"))
+            pred = self._run(src, int(src[1].shape[0]), src[0].device)
+            evaluator.collect_scaled(pred, src[0], self.start_dim, affine[0], affine[1], label_start=src[1])
+        else:
+            pred = self.predict(batch)
+            evaluator.collect_scaled(pred, batch["y"], self.start_dim, affine[0], affine[1])
+        return pred
 
     def gradient_exchange(self):
         """(bucket, leftovers) for the gradient exchange of data-parallel training after ``loss.backward()``:

@@ -230,6 +230,69 @@ def masked_mae_loss(pred: torch.Tensor, y: torch.Tensor, y_start: int, mean: flo
     return _MaskedMAE.apply(pred, y, y_start, mean, std, null_val, min_s, label_start)
 
 
+def _affine_arg(v, n, device, name):
+    """scalar or length-N vector -> (float32 device tensor, per_node flag)"""
+    t = torch.as_tensor(v, dtype=torch.float32).reshape(-1).to(device)
+    if t.numel() not in (1, n):
+        raise _lib.MatgcnError("%s has %d entries, expected 1 or %d (one per node)" % (name, t.numel(), n))
+    return t.contiguous(), int(t.numel() == n and n > 1)
+
+
+def metric_sums(pred: torch.Tensor, y: torch.Tensor, y_start: int = 0, mean=None, std=None, group_mean=None,
+                group_std=None, clamp_min: float = float("nan"), truth_min: float = float("nan"), min_s: float = 1e-4,
+                label_start: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(out, 14) float64 device tensor of the per-horizon sums the evaluator's metrics are ratios of
+    (matgcn_metric_sums, include/matgcn.h): de-scale (mean / std: the scaler, scalar or per node; group_mean /
+    group_std: the per-node group-std re-transform), clamp, select, zero tiny labels and reduce on the device.
+    ``sums``: running sums of earlier batches to add to (several batches = one collect over their concatenation)."""
+    lib = _lib.load()
+    pred = _check_tensor(pred, "pred")
+    b, out, n, od = pred.shape
+    y, label_start, y_steps, y_feat = _label_geometry(pred, y, label_start)
+    sc = _lib.MetricScale()
+    keep = []
+    if (mean is None) != (std is None) or (group_mean is None) != (group_std is None):
+        raise _lib.MatgcnError("mean / std (and group_mean / group_std) come in pairs")
+    if mean is not None:
+        m, pn = _affine_arg(mean, n, pred.device, "mean")
+        sd, pn2 = _affine_arg(std, n, pred.device, "std")
+        if pn != pn2:       # broadcast the scalar one
+            m, sd = (m.expand(n).contiguous() if not pn else m), (sd.expand(n).contiguous() if not pn2 else sd)
+        keep += [m, sd]
+        sc.mean, sc.std, sc.per_node = m.data_ptr(), sd.data_ptr(), int(pn or pn2)
+    if group_mean is not None:
+        gm, _ = _affine_arg(group_mean, n, pred.device, "group_mean")
+        gs, _ = _affine_arg(group_std, n, pred.device, "group_std")
+        gm, gs = gm.expand(n).contiguous(), gs.expand(n).contiguous()
+        keep += [gm, gs]
+        sc.mean2, sc.std2 = gm.data_ptr(), gs.data_ptr()
+    sc.clamp_min, sc.truth_min, sc.min_s = float(clamp_min), float(truth_min), float(min_s)
+    partials = torch.empty(b * out * _lib.METRIC_SUMS, dtype=torch.float64, device=pred.device)
+    accumulate = sums is not None
+    if sums is None:
+        sums = torch.empty(out, _lib.METRIC_SUMS, dtype=torch.float64, device=pred.device)
+    elif tuple(sums.shape) != (out, _lib.METRIC_SUMS) or sums.dtype != torch.float64 or not sums.is_cuda:
+        raise _lib.MatgcnError("sums must be a CUDA float64 tensor of shape (%d, %d)" % (out, _lib.METRIC_SUMS))
+    stream = C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
+    _lib.check(lib.matgcn_metric_sums(C.c_void_p(pred.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(_ptr(label_start)),
+                                      b, out, n, od, y_steps, y_feat, int(y_start), C.byref(sc),
+                                      C.c_void_p(partials.data_ptr()), C.c_void_p(sums.data_ptr()), int(accumulate),
+                                      stream), "matgcn_metric_sums")
+    del keep
+    return sums
+
+
+def metric_table(sums: torch.Tensor, swap_r2: bool = False) -> torch.Tensor:
+    """(2, out, 10) float64 device tensor from (accumulated) metric sums: [0] the evaluator's "single" mode, [1] its
+    "average" mode; metric order _lib.METRICS (matgcn_metric_table)."""
+    out = int(sums.shape[0])
+    table = torch.empty(2, out, len(_lib.METRICS), dtype=torch.float64, device=sums.device)
+    stream = C.c_void_p(torch.cuda.current_stream(sums.device).cuda_stream)
+    _lib.check(_lib.load().matgcn_metric_table(C.c_void_p(sums.data_ptr()), out, int(bool(swap_r2)),
+                                               C.c_void_p(table.data_ptr()), stream), "matgcn_metric_table")
+    return table
+
+
 class HotPath:
     """One (spec, batch) binding.  Not thread-safe; uses torch's current stream at call time."""
 

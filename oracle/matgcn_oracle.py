@@ -361,3 +361,107 @@ def to_tensors(state: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[str, T
 
 def supports_as_tensors(mats: Sequence[np.ndarray], dtype=torch.float32) -> List[Tensor]:
     return [torch.as_tensor(np.asarray(m)).to(dtype) for m in mats]
+
+
+# ----------------------------------------------------------------------------------------------
+# evaluator metrics: TrafficStateEvaluator.collect and the group-std re-transform
+# ----------------------------------------------------------------------------------------------
+EVAL_METRICS = ("MAE", "MAPE", "MSE", "RMSE", "masked_MAE", "masked_MAPE", "masked_MSE", "masked_RMSE", "R2", "EVAR")
+
+
+def _masked_mean(loss: Tensor, label: Tensor, null_val) -> Tensor:
+    """mask = label != null_val (not-NaN for a NaN null value), mask /= mean(mask), NaN -> 0, mean (loss.py:19-29)."""
+    if isinstance(null_val, float) and math.isnan(null_val):
+        mask = ~torch.isnan(label)
+    else:
+        mask = label.ne(null_val)
+    mask = mask.to(loss.dtype)
+    mask = mask / mask.mean()
+    mask = torch.where(torch.isnan(mask), torch.zeros_like(mask), mask)
+    loss = loss * mask
+    loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+    return loss.mean()
+
+
+def _zero_small(label: Tensor, min_s: float) -> Tensor:
+    """labels[|labels| < min_s] = 0 (loss.py:18,53,71,85 - in place in the reference, so every later metric of the same
+    collect() sees the zeroed labels)."""
+    return torch.where(label.abs() < min_s, torch.zeros_like(label), label)
+
+
+def masked_mse(pred: Tensor, label: Tensor, null_val=float("nan"), min_s: float = 1e-4) -> Tensor:
+    """masked_mse_torch (loss.py:70-82)"""
+    label = _zero_small(label, min_s)
+    return _masked_mean(torch.square(pred - label), label, null_val)
+
+
+def masked_rmse(pred: Tensor, label: Tensor, null_val=float("nan"), min_s: float = 1e-4) -> Tensor:
+    """masked_rmse_torch (loss.py:85-88): zeroes with min_s, then masked_mse_torch with ITS default min_s = 1e-4"""
+    return torch.sqrt(masked_mse(pred, _zero_small(label, min_s), null_val))
+
+
+def masked_mape(pred: Tensor, label: Tensor, null_val=float("nan"), min_s: float = 1e-4) -> Tensor:
+    """masked_mape_torch with eps = 0 (loss.py:52-67): |(p-l)/l|; a zero label gives inf (kept) or, with p = l, NaN (-> 0)"""
+    label = _zero_small(label, min_s)
+    return _masked_mean(torch.abs((pred - label) / label), label, null_val)
+
+
+def r2_score(truth: Tensor, pred: Tensor) -> float:
+    """sklearn.metrics.r2_score(y_true, y_pred) on the flattened values (loss.py:91-94): 1 - SS_res / SS_tot, with
+    sklearn's conventions for a constant truth (1 if the residual is zero too, else 0)."""
+    t, p = truth.double().flatten(), pred.double().flatten()
+    res = float(((t - p) ** 2).sum())
+    tot = float(((t - t.mean()) ** 2).sum())
+    return 1.0 - res / tot if tot != 0.0 else (1.0 if res == 0.0 else 0.0)
+
+
+def explained_variance(truth: Tensor, pred: Tensor) -> float:
+    """sklearn.metrics.explained_variance_score(y_true, y_pred) (loss.py:97-100): 1 - Var(t - p) / Var(t)"""
+    t, p = truth.double().flatten(), pred.double().flatten()
+    num = float(((t - p) - (t - p).mean()).pow(2).mean())
+    den = float((t - t.mean()).pow(2).mean())
+    return 1.0 - num / den if den != 0.0 else (1.0 if num == 0.0 else 0.0)
+
+
+def evaluator_table(y_pred: Tensor, y_true: Tensor, mode: str = "single", min_s: float = 1e-4) -> Dict[str, float]:
+    """TrafficStateEvaluator.collect + evaluate for ONE collected batch (traffic_state_evaluator.py:46-131): every
+    metric of EVAL_METRICS at every horizon i, over y[:, i-1] ("single") or y[:, :i] ("average").  The masked_*
+    metrics use null value 0, the plain ones NaN; R2 / EVAR see the labels the loss functions before them zeroed in
+    place (the order of TrafficStateEvaluator.json)."""
+    out: Dict[str, float] = {}
+    for i in range(1, y_true.shape[1] + 1):
+        sl = slice(i - 1, i) if mode == "single" else slice(0, i)
+        p, t = y_pred[:, sl], y_true[:, sl]
+        tz = _zero_small(t, min_s)
+        vals = {"MAE": masked_mae(p, t, float("nan"), min_s), "MAPE": masked_mape(p, t, float("nan"), min_s),
+                "MSE": masked_mse(p, t, float("nan"), min_s), "RMSE": masked_rmse(p, t, float("nan"), min_s),
+                "masked_MAE": masked_mae(p, t, 0.0, min_s), "masked_MAPE": masked_mape(p, t, 0.0, min_s),
+                "masked_MSE": masked_mse(p, t, 0.0, min_s), "masked_RMSE": masked_rmse(p, t, 0.0, min_s),
+                "R2": r2_score(tz, p), "EVAR": explained_variance(tz, p)}
+        for k, v in vals.items():
+            out["%s@%d" % (k, i)] = float(v)
+    return out
+
+
+def groupstd_table(y_pred: Tensor, y_true: Tensor, all_m, all_std, s_small: float = 10.0) -> Dict[str, List[float]]:
+    """The re-transform table of TrafficStateExecutor.evaluate (traffic_state_executor.py:293-322) on de-scaled
+    (B, out, N, od) values: x_t = x * All_std[n] + All_m[n] (:307-308), prediction_t < 0 -> 0 (:312), per ahead step
+    the elements with truth_t > s_small (:316-317), then MAE / MSE / RMSE (the *_np functions, NaN null value: plain
+    means), r2_score(pr, tr) and explained_variance_score(pr, tr) - prediction FIRST, as the reference writes it
+    (:318-319) - and MAPE."""
+    m = torch.as_tensor(all_m, dtype=y_pred.dtype).reshape(1, 1, -1, 1)
+    s = torch.as_tensor(all_std, dtype=y_pred.dtype).reshape(1, 1, -1, 1)
+    pt = y_pred * s + m
+    tt = y_true * s + m
+    pt = torch.where(pt < 0, torch.zeros_like(pt), pt)
+    cols: Dict[str, List[float]] = {k: [] for k in ("MAE", "MSE", "RMSE", "R2", "EVAR", "MAPE")}
+    for rr in range(y_pred.shape[1]):
+        keep = tt[:, rr] > s_small
+        pr, tr = pt[:, rr][keep], tt[:, rr][keep]
+        cols["MAE"].append(float((pr - tr).abs().mean()))
+        cols["MSE"].append(float(torch.square(pr - tr).mean()))
+        cols["RMSE"].append(float(torch.sqrt(torch.square(pr - tr).mean())))
+        cols["R2"].append(r2_score(pr, tr))
+        cols["EVAR"].append(explained_variance(pr, tr))
+        cols["MAPE"].append(float(((pr - tr) / tr).abs().mean()))
+    return cols
