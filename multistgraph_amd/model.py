@@ -104,12 +104,13 @@ class _EncoderParams(nn.Module):
 
 
 def _is_series_batch(batch) -> bool:
-    """a batch of the resident-series loader (multistgraph_amd.dataset.ResidentBatch): carries the device-resident raw
-    series and B label starts instead of materialised windows"""
-    try:
-        return "label_start" in batch and "series" in batch
-    except TypeError:
-        return False
+    """a batch of the resident-series loader (multistgraph_amd.dataset.ResidentBatch), or a plain dict with the same
+    two entries: the device-resident raw series and B label starts instead of materialised windows.  (No ``in`` on
+    foreign objects: the reference's Batch has no __contains__ and raises KeyError on the fallback protocol.)"""
+    from .dataset import ResidentBatch
+    if isinstance(batch, ResidentBatch):
+        return True
+    return isinstance(batch, dict) and "label_start" in batch and "series" in batch
 
 
 class _TrainStep(torch.autograd.Function):
@@ -317,6 +318,9 @@ class MultiATGCN(AbstractTrafficStateModel):
         return _TrainStep.apply(hp, source, mask, h0, tuple(k for k, _ in named), *[p for _, p in named])
 
     def forward(self, batch):
+        if _is_series_batch(batch):    # MTHDatasetResident: windows and labels are gathered on the device (f-2)
+            src = self._batch_source(batch)
+            return self._run(src, int(src[1].shape[0]), src[0].device)
         x = batch["X"]
         assert x.shape[2] == self.num_nodes  # (:195)
         if not x.is_cuda:
@@ -330,7 +334,14 @@ class MultiATGCN(AbstractTrafficStateModel):
         return self.forward(batch)
 
     # ---- the same surface fed from the device-resident raw series (no windows, no labels materialised) ----------
-    def _series_source(self, series: torch.Tensor, label_start, rel_steps):
+    def _batch_source(self, batch):
+        """the (series, label_start, rel_steps) triple of a resident-series batch; its label starts were validated on
+        the host when the loader's table was built (ResidentBatch.range_checked), a plain dict is checked here"""
+        rel = batch.get("rel_steps") if hasattr(batch, "get") else None
+        return self._series_source(batch["series"], batch["label_start"], rel,
+                                   trusted=bool(getattr(batch, "range_checked", False)))
+
+    def _series_source(self, series: torch.Tensor, label_start, rel_steps, trusted: bool = False):
         """(series, int32 device label starts, rel_steps), with the range contract of the series entry points checked
         on the host: every window row and every target row of every sample inside the series (windows.
         check_label_starts).  A host table (numpy / CPU tensor) is checked before it is uploaded; a device tensor costs
@@ -347,6 +358,8 @@ class MultiATGCN(AbstractTrafficStateModel):
             windows.check_label_starts(host, rel_steps, self.output_window, steps)
             return (series, torch.as_tensor(host.astype(np.int32)).to(series.device), rel_steps)
         ls = label_start.to(torch.int32)
+        if trusted:
+            return (series, ls, rel_steps)
         base = ls._base if ls._base is not None else ls      # a row of a validated table is a view of it
         key = (base.data_ptr(), base._version, steps, tuple(int(v) for v in (min(rel_steps), max(rel_steps))))
         if key not in self._valid_label_tables:
@@ -383,11 +396,11 @@ class MultiATGCN(AbstractTrafficStateModel):
     def predict_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
         return self.forward_series(series, label_start, rel_steps)
 
-    def calculate_loss_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+    def calculate_loss_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None, _checked=False):
         """calculate_loss (:422-427) of the batch given by ``label_start``: the prediction from the series-fed forward,
         the targets series[label_start[b] + o] gathered by the loss kernel on the device.  With gradients enabled this is
         the executor's training step (traffic_state_executor.py:411-422) without any host-side window or label."""
-        src = self._series_source(series, label_start, rel_steps)
+        src = self._series_source(series, label_start, rel_steps, trusted=_checked)
         pred = self._run(src, int(src[1].shape[0]), series.device)
         ls = src[1]
         affine = self._affine_scaler()
@@ -399,12 +412,12 @@ class MultiATGCN(AbstractTrafficStateModel):
         y_true = self._scaler.inverse_transform(series[rows][..., self.start_dim:self.end_dim].clone())
         return masked_mae(self._scaler.inverse_transform(pred), y_true, 0)
 
-    def horizon_mae_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
+    def horizon_mae_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None, _checked=False):
         """(out,) MAE@1..MAE@out of the batch given by ``label_start`` (evaluator "single" mode), all on the device."""
         affine = self._affine_scaler()
         if affine is None:
             raise NotImplementedError("horizon_mae_series needs an affine scaler (StandardScaler / NoneScaler)")
-        src = self._series_source(series, label_start, rel_steps)
+        src = self._series_source(series, label_start, rel_steps, trusted=_checked)
         pred = self._run(src, int(src[1].shape[0]), series.device)
         return masked_mae_device(pred, series, self.start_dim, affine[0], affine[1], label_start=src[1])[1:]
 
@@ -417,7 +430,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         if affine is None:
             raise NotImplementedError("collect_metrics needs an affine scaler (StandardScaler / NoneScaler)")
         if _is_series_batch(batch):
-            src = self._series_source(batch["series"], batch["label_start"], batch.get("rel_steps"))
+            src = self._batch_source(batch)
             pred = self._run(src, int(src[1].shape[0]), src[0].device)
             evaluator.collect_scaled(pred, src[0], self.start_dim, affine[0], affine[1], label_start=src[1])
         else:
@@ -453,19 +466,19 @@ class MultiATGCN(AbstractTrafficStateModel):
         return bucket if not rest else None
 
     def _affine_scaler(self):
-        """(mean, std) when the scaler de-scales as x*std + mean with scalar parameters (LibCity's StandardScaler /
-        NoneScaler, libcity/utils/normalization.py:62-76), else None."""
+        """(mean, std) when the scaler de-scales as x*std + mean with scalar parameters - LibCity's StandardScaler,
+        NoneScaler, NormalScaler, MinMax01Scaler, MinMax11Scaler (libcity/utils/normalization.py:20-113) all do -,
+        else None (LogScaler).  Found by probing inverse_transform at three points, so any scaler object works."""
         sc = self._scaler
-        mean, std = getattr(sc, "mean", None), getattr(sc, "std", None)
-        if mean is None and std is None and type(sc).__name__ == "NoneScaler":
-            return 0.0, 1.0
-        try:
-            mean, std = float(mean), float(std)
-        except (TypeError, ValueError):
+        if sc is None:
             return None
-        probe = sc.inverse_transform(torch.tensor([0.0, 1.0]))
-        if abs(float(probe[0]) - mean) > 1e-6 * max(1.0, abs(mean)) or \
-                abs(float(probe[1]) - (mean + std)) > 1e-6 * max(1.0, abs(mean + std)):
+        try:
+            probe = sc.inverse_transform(torch.tensor([0.0, 1.0, 2.0], dtype=torch.float64))
+            f0, f1, f2 = (float(v) for v in probe)
+        except Exception:
+            return None
+        mean, std = f0, f1 - f0
+        if not all(math.isfinite(v) for v in (f0, f1, f2)) or abs(f2 - (mean + 2.0 * std)) > 1e-9 * max(1.0, abs(f2)):
             return None
         return mean, std
 
@@ -473,6 +486,9 @@ class MultiATGCN(AbstractTrafficStateModel):
         """de-scale prediction and label, masked MAE with null value 0 (:422-427).  With an affine scaler the
         de-scale + mask + reduction run fused on the device; any other scaler takes the reference's torch
         arithmetic on the HIP prediction."""
+        if _is_series_batch(batch):
+            src = self._batch_source(batch)
+            return self.calculate_loss_series(src[0], src[1], src[2], _checked=True)
         y_true = batch["y"]
         y_predicted = self.predict(batch)
         affine = self._affine_scaler()
@@ -490,5 +506,8 @@ class MultiATGCN(AbstractTrafficStateModel):
         affine = self._affine_scaler()
         if affine is None:
             raise NotImplementedError("horizon_mae needs an affine scaler (StandardScaler / NoneScaler)")
+        if _is_series_batch(batch):
+            src = self._batch_source(batch)
+            return self.horizon_mae_series(src[0], src[1], src[2], _checked=True)
         pred = self.predict(batch)
         return masked_mae_device(pred, batch["y"], self.start_dim, affine[0], affine[1])[1:]
