@@ -276,31 +276,31 @@ def test_one_epoch_over_the_resident_dataset(lib_built, monkeypatch):
     want = O.evaluator_table(torch.cat(preds), torch.cat(trues), "single")
     for k, v in want.items():
         assert (np.isinf(v) and np.isinf(res[k])) or abs(res[k] - v) <= 1e-4 * abs(v) + 1e-7, k
-    # a few training steps: the loss of the series path trains (gradients flow, loss moves)
+    # a training step: the series path and the same samples as materialised windows give the same loss and gradients;
+    # then a few optimizer steps on that batch: the loss moves down (gradients flow through the series path)
     m.train()
     monkeypatch.setattr(torch.nn.functional, "dropout", lambda inp, p=0.5, training=True, inplace=False: inp)
     opt = torch.optim.Adam(m.parameters(), lr=2e-3)
     torch.manual_seed(0)
+    batch = next(iter(train))
+    batch.to_tensor(dev)
+    win = {"X": batch["X"].clone(), "y": batch["y"].clone()}
+    opt.zero_grad()
+    loss = m.calculate_loss(batch)
+    loss.backward()
+    g_series = {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
+    opt.zero_grad()
+    lw = m.calculate_loss(win)
+    lw.backward()
+    assert abs(float(lw.detach()) - float(loss.detach())) <= 1e-6 * abs(float(loss.detach()))
+    for k, q in m.named_parameters():
+        if q.grad is not None:
+            assert max_norm_err(q.grad.cpu().numpy(), g_series[k].cpu().numpy()) <= 1e-5, k
     losses = []
-    for i, batch in enumerate(train):
+    for _ in range(6):
         opt.zero_grad()
-        batch.to_tensor(dev)
-        loss = m.calculate_loss(batch)
-        if i == 0:      # the same step on materialised windows gives the same loss and gradients
-            ls = batch._host_starts.astype(np.int64)
-            win = {"X": batch["X"].clone(), "y": batch["y"].clone()}
-        loss.backward()
-        if i == 0:
-            g_series = {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
-            opt.zero_grad()
-            lw = m.calculate_loss(win)
-            lw.backward()
-            assert abs(float(lw) - float(loss)) <= 1e-6 * abs(float(loss))
-            for k, q in m.named_parameters():
-                if q.grad is not None:
-                    assert max_norm_err(q.grad.cpu().numpy(), g_series[k].cpu().numpy()) <= 1e-5, k
+        step_loss = m.calculate_loss(batch)
+        step_loss.backward()
         opt.step()
-        losses.append(float(loss))
-        if i >= 5:
-            break
-    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+        losses.append(float(step_loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

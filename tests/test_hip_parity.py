@@ -339,7 +339,12 @@ def test_forward_synth4096(lib_built):
     got = hp.forward(torch.from_numpy(c.x).to(dev))
     assert got.shape == c.gold["pred"].shape
     assert max_norm_err(got.cpu().numpy(), c.gold["pred"]) <= E2E_TOL
-    assert elementwise_excess(got.cpu().numpy(), c.gold["pred"]) <= 1.0, elementwise_excess(got.cpu().numpy(), c.gold["pred"])
+    # element-wise with the absolute floor scaled by sqrt(N / 403): the fp32 rounding noise of an N-term graph-mix row
+    # grows like sqrt(N) - the reference's OWN fp32-vs-fp64 gap is 8e-7 of max|y| at N = 403, i.e.
+    # ~2.5e-6 at N = 4096, and the golden vector is that fp32 result (measured here: 1.8e-6 of max|y| near zero crossings)
+    floor = 1e-6 * (c.n / 403.0) ** 0.5
+    excess = elementwise_excess(got.cpu().numpy(), c.gold["pred"], floor=floor)
+    assert excess <= 1.0, excess
     res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0, null_val=0.0).cpu().numpy()
     assert abs(res[0] - float(c.gold["loss"])) <= 1e-4 * abs(float(c.gold["loss"]))
     res = masked_mae_device(got, torch.from_numpy(c.y).to(dev), 0, 0.0, 1.0).cpu().numpy()
