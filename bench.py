@@ -81,6 +81,33 @@ def executed_flops_per_unit(n, ks, c0=2, h=64, out=24, steps=24):
     return total + 2 * h * out
 
 
+def backward_executed_flops(n, b, ks, k_total, c0=2, h=64, out=24, steps=24, layers=2, d=20):
+    """What the kernels of matgcn_backward multiply for one batch (every product counted once, unpadded):
+    chain - residual-cell transposes, the two transposed node contractions over the 1 + ks kept slots, two transposed
+    graph mixes per (layer, step); x columns (node contraction of 192 columns; layer 0: its c0 channels, mixed back
+    once over all steps; upper layers ride in the gate block of the layer below, only the sequence's last step is
+    mixed back by itself); node-adaptive weight gradients; the adjacency gradient of the ONE learned support (the
+    static supports' mixes have none); residual nn.Linear gradients; pools and node embedding; head."""
+    rows = n * b
+    total = 0.0
+    for l in range(layers):
+        c = c0 if l == 0 else h
+        i_l = c + h
+        per_step = (2.0 * rows * 3 * h * i_l                      # residual cell: d pre (128 + 64 columns) x W^T
+                    + 2.0 * rows * h * h * (1 + ks)               # update block: h columns of the kept slots
+                    + 2.0 * rows * 2 * h * h * (1 + ks)           # gate block
+                    + 2 * 2.0 * ks * n * n * b * h)               # two transposed mixes
+        x_cols = 2.0 * rows * 3 * h * c * (1 + ks)               # x columns of both AGCNs (192 pre-activation columns)
+        x_mix = 2.0 * ks * n * n * b * c * (1.0 if l == 0 else 1.0 / steps)
+        w_grad = 2.0 * rows * (1 + ks) * i_l * 3 * h             # dW[n][slot][i][o] over the step's rows
+        adj = 2.0 * n * n * b * (2 * h + (c if l == 0 else h / steps))   # adaptive support: gate + update (+ own x part)
+        lin = 2.0 * rows * i_l * 3 * h                            # residual nn.Linear weight gradients
+        total += steps * (per_step + x_cols + x_mix + w_grad + adj + lin)
+        total += 2 * 2.0 * n * d * k_total * i_l * 3 * h          # pools + node embedding from the node weight gradients
+    total += 2 * 2.0 * rows * steps * h * out                     # head: weight gradient and sequence gradient
+    return total
+
+
 def algorithmic_bytes_per_unit(c0=2, h=64, elem=4):
     return elem * ((2 * c0 + 7 * h) + (2 * h + 7 * h))
 
@@ -533,12 +560,15 @@ def main():
             ts = train_step_times(model, batch, w)
             # every forward GEMM has two backward GEMMs (input gradient, weight gradient): the backward executes ~2x the
             # forward's EXECUTED FLOPs (dense supports only, shared mixes) - not 2x the SURVEY formula
-            bwd_flops = 2.0 * exec_unit * w["batch"] * 24 * w["nodes"]
+            bwd_flops = backward_executed_flops(w["nodes"], w["batch"], ks, spec.k_total, out=w["out"])
+            ts["backward_executed_gflop"] = bwd_flops / 1e9
             ts["backward_executed_tflops"] = bwd_flops / (ts["backward_ms"] * 1e-3) / 1e12
             ts["backward_frac_mfma"] = ts["backward_executed_tflops"] / PEAK_MFMA_F32_TFLOPS
-            ts["backward_flops_note"] = ("2 x the forward's executed FLOPs per node-step (%.0f) / backward time: an upper "
-                                         "bound of what the backward multiplies (the mixes of the static supports have no "
-                                         "adjacency-gradient GEMM), i.e. a time ratio rather than a utilisation" % exec_unit)
+            ts["backward_over_forward_flops"] = bwd_flops / (exec_unit * w["batch"] * 24 * w["nodes"])
+            ts["backward_flops_note"] = ("executed FLOPs of matgcn_backward by the kernel models of "
+                                         "bench.backward_executed_flops (every product once, unpadded; only the learned "
+                                         "support has an adjacency-gradient GEMM) / backward time: a utilisation of the "
+                                         "dense fp32 MFMA peak")
             if cpu_train is not None:
                 ts["cpu_baseline"] = cpu_train
                 ts["gpu_over_cpu"] = ts["node_steps_per_s"] / cpu_train["value"]

@@ -455,8 +455,8 @@ struct Ctx {
 
 // dynamic LDS: k_gate16 48 KB (state chunk + two ping-pong chunks), k_update16 64 KB (+ the x_t tile of the residual
 // cell), k_px16 the whole tile; sizes above 64 KB must be opted into once per kernel
-constexpr int GATE_LDS = 3 * 4096 * (int)sizeof(float);
-constexpr int UPDATE_LDS = 4 * 4096 * (int)sizeof(float);
+constexpr int GATE_LDS = 3 * NODE_ROWS * 64 * (int)sizeof(float);
+constexpr int UPDATE_LDS = 4 * NODE_ROWS * 64 * (int)sizeof(float);
 int node_kernels_ready(int ldsBytes) {
   static int readyOn[MAX_DEVICES] = {0};   // function attributes are per device
   int dev = 0;
@@ -464,13 +464,13 @@ int node_kernels_ready(int ldsBytes) {
   int& ready = readyOn[dev];
   if (ready >= ldsBytes) return MATGCN_OK;
   const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false>), at, GATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true>), at, GATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, NODE_ROWS>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true, NODE_ROWS>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true, NODE_ROWS>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -575,7 +575,7 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   a.g = G; a.gNodeStride = phase == 1 ? gNodeStride : 0; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
   else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.RB * NODE_PX_BLOCK;
-  const dim3 grid((unsigned)P.N, (unsigned)P.RB);
+  const dim3 grid(node_items(P.N, P.B, NODE_ROWS));   // (node, NODE_ROWS-row block) work items, XCD-paired per node
   const bool save = c.train != nullptr && res != nullptr;
   if (save) {
     const size_t at = (size_t)t * P.B * P.Np * H;
@@ -585,8 +585,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   if (phase == 1) {
     a.s = Hx; a.w = c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    if (save) hipLaunchKernelGGL(k_gate16<true>, grid, dim3(512), GATE_LDS, s, a);
-    else hipLaunchKernelGGL(k_gate16<false>, grid, dim3(512), GATE_LDS, s, a);
+    if (save) hipLaunchKernelGGL((k_gate16<true, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
+    else hipLaunchKernelGGL((k_gate16<false, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     return launch_ok();
   }
   a.s = ZHx; a.w = c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
@@ -595,10 +595,10 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    if (save) hipLaunchKernelGGL((k_update16<1, true>), grid, dim3(512), UPDATE_LDS, s, a);
-    else hipLaunchKernelGGL((k_update16<1, false>), grid, dim3(512), UPDATE_LDS, s, a);
+    if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
+    else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
-    hipLaunchKernelGGL((k_update16<0, false>), grid, dim3(512), UPDATE_LDS, s, a);
+    hipLaunchKernelGGL((k_update16<0, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   }
   return launch_ok();
 }
@@ -623,7 +623,7 @@ int res_step(const Ctx& c, int l, const float* xt, long xRowStride) {
   a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   fill_res_args(c, l, xt, xRowStride, nullptr, nullptr, &a);
   ProfScope prof(MATGCN_PROF_RES, c.s);
-  hipLaunchKernelGGL((k_update16<2, false>), dim3((unsigned)P.N, (unsigned)P.RB), dim3(512), UPDATE_LDS, c.s, a);
+  hipLaunchKernelGGL((k_update16<2, false, NODE_ROWS>), dim3(node_items(P.N, P.B, NODE_ROWS)), dim3(512), UPDATE_LDS, c.s, a);
   return launch_ok();
 }
 
@@ -688,13 +688,13 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
         else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
         {
           ProfScope prof(MATGCN_PROF_RES, cs);
-          const dim3 grid((unsigned)P.N, (unsigned)((P.B + 63) / 64));
+          const dim3 grid(node_items(P.N, P.B, NODE_ROWS));
           if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
             const size_t at = (size_t)t * P.B * P.Np * H;
             a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
-            hipLaunchKernelGGL((k_update16<2, true>), grid, dim3(512), UPDATE_LDS, cs, a);
+            hipLaunchKernelGGL((k_update16<2, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
           } else {
-            hipLaunchKernelGGL((k_update16<2, false>), grid, dim3(512), UPDATE_LDS, cs, a);
+            hipLaunchKernelGGL((k_update16<2, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
           }
         }
         CHECK_LAUNCH();

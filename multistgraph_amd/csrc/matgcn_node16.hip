@@ -40,8 +40,16 @@
 #endif
 // (the weight ring of the K loop runs one 64-wide K chunk = 4 k-groups ahead of the MFMAs: 32-64 MFMAs per wave and
 // chunk, shared by up to four waves per SIMD, cover the round trip)
+#ifndef NODE_MIN_WAVES_32
+#define NODE_MIN_WAVES_32 4   // the 32-row instantiations of k_gate16 / k_update16
+#endif
 #ifndef PX16_RING
 #define PX16_RING 4        // k_px16: two rings (two column tiles per wave)
+#endif
+#ifndef NODE_ROWS
+#define NODE_ROWS 64       // rows (batch items) of one (node, row block) work item of k_gate16 / k_update16: 64 or 32.
+                           // The fragment-ordered PX / R blocks stay 64-row blocks either way (a 32-row item is the
+                           // lower or upper pair of row tiles of its block).
 #endif
 #define NODE_PX_BLOCK 12288   // floats of one fragment-ordered PX block: 12 column tiles x 4 row tiles x 64 lanes x 4
 #define NODE_R_BLOCK 4096     // floats of one fragment-ordered R block: 4 column tiles x 4 row tiles x 64 lanes x 4
@@ -107,18 +115,26 @@ __device__ __forceinline__ int swz(int row, int col, int spr) {
 
 // ---- K-chunk pipeline shared by k_gate16 and k_update16 --------------------------------------------------------
 // staging coordinates of a thread: rows srow and srow + 32 of a chunk, 16-byte slot sq
+// a ROWS-row chunk is ROWS x 16 slots = ROWS/32 float4 per thread of the 512: sweep it of a thread is row srow + 32 it
+template <int ROWS>
 struct ChunkStage {
-  int srow, sq, gA, gB;      // gA / gB: the two global rows (clamped into range: loads are never predicated, a
-  bool vA, vB;               //          predicated load would make the compiler wait for each one separately)
+  static constexpr int NS = ROWS / 32;
+  int srow, sq;
+  int g[NS];                 // the global rows (clamped into range: loads are never predicated, a predicated load
+  bool v[NS];                //                  would make the compiler wait for each one separately)
   const float4* gsrc;        // this node's mixed rows [rows][Ks][16 slots]
   int spr;                   // slots per mixed row = 16 * Ks
 };
 
-__device__ __forceinline__ ChunkStage chunk_stage(const Node16Args& a, int n, int rowBase) {
-  ChunkStage c;
+template <int ROWS>
+__device__ __forceinline__ ChunkStage<ROWS> chunk_stage(const Node16Args& a, int n, int rowBase) {
+  ChunkStage<ROWS> c;
   c.srow = threadIdx.x >> 4; c.sq = threadIdx.x & 15;
-  c.vA = rowBase + c.srow < a.rows; c.vB = rowBase + c.srow + 32 < a.rows;
-  c.gA = min(rowBase + c.srow, a.rows - 1); c.gB = min(rowBase + c.srow + 32, a.rows - 1);
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    c.v[it] = rowBase + c.srow + 32 * it < a.rows;
+    c.g[it] = min(rowBase + c.srow + 32 * it, a.rows - 1);
+  }
   c.spr = 16 * a.Ks;
   c.gsrc = reinterpret_cast<const float4*>(
       a.g + (size_t)n * (a.gNodeStride ? (size_t)a.gNodeStride : (size_t)a.rows * c.spr * 4));
@@ -126,17 +142,21 @@ __device__ __forceinline__ ChunkStage chunk_stage(const Node16Args& a, int n, in
 }
 
 // request chunk c (1..Ks) = mixed slot c-1 of this node's rows
-__device__ __forceinline__ void chunk_load(const ChunkStage& c, int Ks, int chunk, float4 (&r)[2]) {
+template <int ROWS>
+__device__ __forceinline__ void chunk_load(const ChunkStage<ROWS>& c, int Ks, int chunk, float4 (&r)[ROWS / 32]) {
   const int k = max(min(chunk, Ks) - 1, 0);
-  r[0] = c.gsrc[(size_t)c.gA * c.spr + k * 16 + c.sq];
-  r[1] = c.gsrc[(size_t)c.gB * c.spr + k * 16 + c.sq];
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) r[it] = c.gsrc[(size_t)c.g[it] * c.spr + k * 16 + c.sq];
 }
 
-// registers -> one [64 rows][16 slots] swizzled LDS chunk; rows beyond a.rows are zero
-__device__ __forceinline__ void chunk_store(float* buf, const ChunkStage& c, const float4& ra, const float4& rb) {
-  const int rA = c.srow, rB = c.srow + 32;
-  *reinterpret_cast<float4*>(&buf[(rA * 16 + (c.sq ^ (rA & 15))) * 4]) = keep4(c.vA, ra);
-  *reinterpret_cast<float4*>(&buf[(rB * 16 + (c.sq ^ (rB & 15))) * 4]) = keep4(c.vB, rb);
+// registers -> one [ROWS][16 slots] swizzled LDS chunk; rows beyond a.rows are zero
+template <int ROWS>
+__device__ __forceinline__ void chunk_store(float* buf, const ChunkStage<ROWS>& c, const float4 (&r)[ROWS / 32]) {
+#pragma unroll
+  for (int it = 0; it < ROWS / 32; ++it) {
+    const int rr = c.srow + 32 * it;
+    *reinterpret_cast<float4*>(&buf[(rr * 16 + (c.sq ^ (rr & 15))) * 4]) = keep4(c.v[it], r[it]);
+  }
 }
 
 // The four k-groups of one chunk for NRT row tiles starting at tile rt0.  The weights of a chunk wait in one HALF of
@@ -192,50 +212,53 @@ __device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int
 //              for c = 1..Ks-1:  request the weights of chunk c+1, chunk c from Gb[(c-1)&1];  barrier;
 //                                Gb[(c-1)&1] <- chunk c+2, request chunk c+4
 //              late();  chunk Ks
-template <int NRT, typename Late>
+template <int ROWS, int NRT, typename Late>
 __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowBase, float* Hs, float* Gb, int rt0, int j,
                                             int kq, const float4* wp, size_t gStride, f32x4 (&acc)[NRT], Late&& late) {
+  constexpr int NS = ROWS / 32, CH = ROWS * 64;      // float4 per thread and chunk; floats of one LDS chunk
   const int Ks = a.Ks, gLast = 4 * (1 + Ks) - 1;
-  const ChunkStage cs = chunk_stage(a, n, rowBase);
-  const float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gA * a.Np + n) * 64 + cs.sq * 4);
-  const float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gB * a.Np + n) * 64 + cs.sq * 4);
+  const ChunkStage<ROWS> cs = chunk_stage<ROWS>(a, n, rowBase);
+  float4 hS[NS];
+#pragma unroll
+  for (int it = 0; it < NS; ++it)
+    hS[it] = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.g[it] * a.Np + n) * 64 + cs.sq * 4);
   float4 wr[2][4];       // weight ring: chunk c reads half c & 1
 #pragma unroll
   for (int r = 0; r < 4; ++r) wr[0][r] = wp[(size_t)min(r, gLast) * gStride];
   // staging registers: chunk c waits in st[c & 1].  Every request below is UNCONDITIONAL (the chunk index is clamped, a
   // request past the last chunk re-reads it from L2): a load behind a branch makes the number of loads in flight depend
   // on the path, and the compiler then drains the whole queue (vmcnt(0)) where the paths meet - at the loop head
-  float4 st[2][2];
-  chunk_load(cs, Ks, 1, st[1]);
-  chunk_load(cs, Ks, 2, st[0]);
+  float4 st[2][NS];
+  chunk_load<ROWS>(cs, Ks, 1, st[1]);
+  chunk_load<ROWS>(cs, Ks, 2, st[0]);
 #pragma unroll
   for (int q = 0; q < NRT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  chunk_store(Hs, cs, hA, hB);
+  chunk_store<ROWS>(Hs, cs, hS);
   __syncthreads();
   if (Ks > 0) {
     chunk_mfma<NRT, 0, true>(Hs, rt0, j, kq, wr, wp, gStride, 4, gLast, acc);
-    chunk_store(Gb, cs, st[1][0], st[1][1]);
-    if (Ks > 1) chunk_store(Gb + 4096, cs, st[0][0], st[0][1]);
-    chunk_load(cs, Ks, 3, st[1]);
-    chunk_load(cs, Ks, 4, st[0]);
+    chunk_store<ROWS>(Gb, cs, st[1]);
+    if (Ks > 1) chunk_store<ROWS>(Gb + CH, cs, st[0]);
+    chunk_load<ROWS>(cs, Ks, 3, st[1]);
+    chunk_load<ROWS>(cs, Ks, 4, st[0]);
     __syncthreads();
     for (int c = 1; c < Ks; c += 2) {
       // odd chunk c (not the last) in Gb[0]; afterwards Gb[0] <- chunk c+2 (waiting in st[1])
       chunk_mfma<NRT, 1, true>(Gb, rt0, j, kq, wr, wp, gStride, 4 * (c + 1), gLast, acc);
       __syncthreads();
-      if (c + 2 <= Ks) chunk_store(Gb, cs, st[1][0], st[1][1]);
-      chunk_load(cs, Ks, c + 4, st[1]);
+      if (c + 2 <= Ks) chunk_store<ROWS>(Gb, cs, st[1]);
+      chunk_load<ROWS>(cs, Ks, c + 4, st[1]);
       if (c + 1 < Ks) {  // even chunk c+1 (not the last) in Gb[1]; afterwards Gb[1] <- chunk c+3 (waiting in st[0])
-        chunk_mfma<NRT, 0, true>(Gb + 4096, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
+        chunk_mfma<NRT, 0, true>(Gb + CH, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
         __syncthreads();
-        if (c + 3 <= Ks) chunk_store(Gb + 4096, cs, st[0][0], st[0][1]);
-        chunk_load(cs, Ks, c + 5, st[0]);
+        if (c + 3 <= Ks) chunk_store<ROWS>(Gb + CH, cs, st[0]);
+        chunk_load<ROWS>(cs, Ks, c + 5, st[0]);
       }
     }
   }
   late();
   if (Ks & 1) chunk_mfma<NRT, 1, false>(Gb, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);               // odd last chunk
-  else chunk_mfma<NRT, 0, false>(Ks > 0 ? Gb + 4096 : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
+  else chunk_mfma<NRT, 0, false>(Ks > 0 ? Gb + CH : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
 }
 
 // layer-0 x part: acc[q] += XA[rows of tile rt0+q][16 gx .. +16] . Wx[gx]; A fragments come straight from global
@@ -264,43 +287,58 @@ __device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase
 
 __device__ __forceinline__ f32x4 as_f32x4(const float4& v) { return f32x4{v.x, v.y, v.z, v.w}; }
 
+// work item id -> (node, row block): the row blocks of one node get ids 8 apart - the same XCD under round-robin
+// dispatch and adjacent in time, so every block after the first finds the node's weights in that XCD's L2
+__device__ __forceinline__ bool node_item(int id, int blocks, int N, int& n, int& rbr) {
+  const int grp = id / (8 * blocks), rem = id - grp * 8 * blocks;
+  n = grp * 8 + (rem & 7); rbr = rem >> 3;
+  return n < N;
+}
+inline unsigned node_items(int N, int rows, int blockRows) {
+  return (unsigned)((N + 7) / 8 * 8 * ((rows + blockRows - 1) / blockRows));
+}
+
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
-// wave w = column tile w of 8 (0..3: z, 4..7: r), all four row tiles.  LDS 48 KB: Hs | Gb[2]
-template <bool SAVE>
-__global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_gate16(Node16Args a) {
+// wave w = column tile w of 8 (0..3: z, 4..7: r), all ROWS/16 row tiles.  LDS 3 chunks of ROWS x 64 floats: Hs | Gb[2]
+template <bool SAVE, int ROWS>
+__global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_32) void k_gate16(Node16Args a) {
+  constexpr int NRT = ROWS / 16, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Hs = lds;               // [64][16 slots] the state rows: chunk 0, and the h of z*h
-  float* Gb = lds + 4096;        // 2 x [64][16 slots] mixed-slot chunks; afterwards the z*h output tile
-  const int n = blockIdx.x, rb = blockIdx.y, RB = gridDim.y, rowBase = rb * 64;
+  float* Hs = lds;               // [ROWS][16 slots] the state rows: chunk 0, and the h of z*h
+  float* Gb = lds + CH;          // 2 x [ROWS][16 slots] mixed-slot chunks; afterwards the z*h output tile
+  int n, rbr;
+  if (!node_item(blockIdx.x, (a.rows + ROWS - 1) / ROWS, a.N, n, rbr)) return;
+  const int rowBase = rbr * ROWS;
+  const int RB = (a.rows + 63) >> 6, rb = rowBase >> 6, rtb = (rowBase & 63) >> 4;   // 64-row block of PX / R, first row tile in it
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + a.Ks);
   const size_t gStride = 8 * 64;
   const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
-  f32x4 acc[4];
-  float4 pxv[4];                 // hoisted pre-activation (x rows + bias) in fragment order, added in the epilogue
-  node_k_loop<4>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
+  f32x4 acc[NRT];
+  float4 pxv[NRT];               // hoisted pre-activation (x rows + bias) in fragment order, added in the epilogue
+  node_k_loop<ROWS, NRT>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
     if (a.px) {
-      const float4* pf = reinterpret_cast<const float4*>(a.px) + (((size_t)n * RB + rb) * 12 + w) * 4 * 64 + lane;
+      const float4* pf = reinterpret_cast<const float4*>(a.px) + ((((size_t)n * RB + rb) * 12 + w) * 4 + rtb) * 64 + lane;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) pxv[rt] = pf[rt * 64];
+      for (int rt = 0; rt < NRT; ++rt) pxv[rt] = pf[rt * 64];
     } else {   // layer 0 contracts its narrow x part here, straight from global memory
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) pxv[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      x_groups<4>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
+      for (int rt = 0; rt < NRT; ++rt) pxv[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      x_groups<NRT>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
     }
   });
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
     acc[rt][0] += pxv[rt].x; acc[rt][1] += pxv[rt].y; acc[rt][2] += pxv[rt].z; acc[rt][3] += pxv[rt].w;
   }
   // epilogue: zr = sigmoid(.);  r leaves in fragment order straight from the accumulators (the update kernel of
-  // this node reads it back the same way); z*h is gathered as a [64][64] tile in LDS (the chunk buffers are dead once
+  // this node reads it back the same way); z*h is gathered as a [ROWS][64] tile in LDS (the chunk buffers are dead once
   // every wave has left the K loop) and written out as whole 256-byte rows of the next mix's operand
   __syncthreads();
   float* Out = Gb;
   const int o = 16 * w + j;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
@@ -313,14 +351,14 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_gate16(Node16Args a) {
     }
   }
   if (w >= 4) {
-    const size_t base = ((((size_t)n * RB + rb) * 4 + (w - 4)) * 4) * 256 + (size_t)lane * 4;
+    const size_t base = (((((size_t)n * RB + rb) * 4 + (w - 4)) * 4) + rtb) * 256 + (size_t)lane * 4;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
       store_wt16(a.r, base + (size_t)rt * 256, make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]));
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {                  // 64 rows x 16 slots = 1024 float4 over 512 threads
+  for (int it = 0; it < ROWS / 32; ++it) {          // ROWS rows x 16 slots float4 over 512 threads
     const int lb = (tid >> 4) + 32 * it, q = tid & 15, b = rowBase + lb;
     if (b >= a.rows) continue;
     const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (q ^ (lb & 15))) * 4]);
@@ -344,27 +382,28 @@ struct Px16Args {
 
 // stage the whole 64-row A tile of a (node, step, row block): Hs <- x rows (16 slots), Gs <- G rows (16*Ks slots)
 __device__ __forceinline__ void stage_node_tile(const Node16Args& a, int n, int rowBase, float* Hs, float* Gs) {
-  const ChunkStage cs = chunk_stage(a, n, rowBase);
-  const float4 hA = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gA * a.Np + n) * 64 + cs.sq * 4);
-  const float4 hB = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.gB * a.Np + n) * 64 + cs.sq * 4);
+  const ChunkStage<64> cs = chunk_stage<64>(a, n, rowBase);
+  float4 hS[2];
+  hS[0] = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.g[0] * a.Np + n) * 64 + cs.sq * 4);
+  hS[1] = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.g[1] * a.Np + n) * 64 + cs.sq * 4);
   const int rA = cs.srow, rB = cs.srow + 32;
   const int pA = cs.sq ^ (rA & 15), pB = cs.sq ^ (rB & 15);
   const int spr = cs.spr;
-  if (a.Ks == 0) chunk_store(Hs, cs, hA, hB);
+  if (a.Ks == 0) chunk_store<64>(Hs, cs, hS);
   for (int k0 = 0; k0 < a.Ks; k0 += 4) {
     float4 vAk[4], vBk[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int k = min(k0 + kk, a.Ks - 1);
-      vAk[kk] = cs.gsrc[(size_t)cs.gA * spr + k * 16 + cs.sq];
-      vBk[kk] = cs.gsrc[(size_t)cs.gB * spr + k * 16 + cs.sq];
+      vAk[kk] = cs.gsrc[(size_t)cs.g[0] * spr + k * 16 + cs.sq];
+      vBk[kk] = cs.gsrc[(size_t)cs.g[1] * spr + k * 16 + cs.sq];
     }
-    if (k0 == 0) chunk_store(Hs, cs, hA, hB);
+    if (k0 == 0) chunk_store<64>(Hs, cs, hS);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (k0 + kk < a.Ks) {
-        *reinterpret_cast<float4*>(&Gs[(rA * spr + (k0 + kk) * 16 + pA) * 4]) = keep4(cs.vA, vAk[kk]);
-        *reinterpret_cast<float4*>(&Gs[(rB * spr + (k0 + kk) * 16 + pB) * 4]) = keep4(cs.vB, vBk[kk]);
+        *reinterpret_cast<float4*>(&Gs[(rA * spr + (k0 + kk) * 16 + pA) * 4]) = keep4(cs.v[0], vAk[kk]);
+        *reinterpret_cast<float4*>(&Gs[(rB * spr + (k0 + kk) * 16 + pB) * 4]) = keep4(cs.v[1], vBk[kk]);
       }
     }
   }
@@ -454,18 +493,23 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
 // ---- update AGCN + tanh + GRU blend, fused with the residual GRU cell and the per-step blend ------------------
 // MODE 0: ATGRU update only (h' out); 1: update + residual cell (+ blend); 2: residual cell only on s (unit entry)
 //
-// Waves: (ct = w&3, rh = w>>2) = column tile ct of 4, row tiles 2rh and 2rh+1, the whole K range (the two waves of a
-// column tile request the same weight fragments: the second request is an L1 / L2 hit, HBM sees each byte once).
-// The residual cell then runs two small GEMMs on tiles that never leave LDS.  LDS 64 KB: Hs | Gb[2] | X
-template <int MODE, bool SAVE>
-__global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) {
+// Waves: (ct = w&3, rh = w>>2) = column tile ct of 4, row tiles of half rh (ROWS/32 of them), the whole K range (the
+// two waves of a column tile request the same weight fragments: the second request is an L1 / L2 hit, HBM sees each
+// byte once).  The residual cell then runs two small GEMMs on tiles that never leave LDS.
+// LDS 4 chunks of ROWS x 64 floats: Hs | Gb[2] | X
+template <int MODE, bool SAVE, int ROWS>
+__global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_32) void k_update16(Node16Args a) {
+  constexpr int NRT = ROWS / 16, NR2 = ROWS / 32, NS = ROWS / 32, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Hs = lds;               // [64][16 slots]: z*h (chunk 0) during the update GEMM, then h'
-  float* Gb = lds + 4096;        // 2 x [64][16 slots] mixed-slot chunks; reused by the residual cell:
-  float* ZH2 = Gb;               //   [64][16 slots] z2*h'
-  float* R2 = Gb + 4096;         //   [64][16 slots] r2
-  float* XT = lds + 3 * 4096;    // [64][16 slots] x_t (zero padded); afterwards the output tile
-  const int n = blockIdx.x, rb = blockIdx.y, RB = gridDim.y, rowBase = rb * 64;
+  float* Hs = lds;               // [ROWS][16 slots]: z*h (chunk 0) during the update GEMM, then h'
+  float* Gb = lds + CH;          // 2 x [ROWS][16 slots] mixed-slot chunks; reused by the residual cell:
+  float* ZH2 = Gb;               //   [ROWS][16 slots] z2*h'
+  float* R2 = Gb + CH;           //   [ROWS][16 slots] r2
+  float* XT = lds + 3 * CH;      // [ROWS][16 slots] x_t (zero padded); afterwards the output tile
+  int n, rbr;
+  if (!node_item(blockIdx.x, (a.rows + ROWS - 1) / ROWS, a.N, n, rbr)) return;
+  const int rowBase = rbr * ROWS;
+  const int RB = (a.rows + 63) >> 6, rb = rowBase >> 6, rtb = (rowBase & 63) >> 4;   // 64-row block of PX / R, first row tile in it
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int ct = w & 3, rh = w >> 2;
   const int srow = tid >> 4, sq = tid & 15;   // staging coordinates: 32 rows x 16 slots per sweep
@@ -475,39 +519,43 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
     const int nG = 4 * (1 + a.Ks);
     const size_t gStride = 4 * 64;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
-    f32x4 acc[2];
+    f32x4 acc[NR2];
     // epilogue operands, requested just before the last chunk: PX and r in fragment order (r as k_gate16 left it),
     // the previous state row-major
-    float4 pxv[2], rv[2];
-    float hv[2][4];
-    node_k_loop<2>(a, n, rowBase, Hs, Gb, 2 * rh, j, kq, wp, gStride, acc, [&]() {
+    float4 pxv[NR2], rv[NR2];
+    float hv[NR2][4];
+    node_k_loop<ROWS, NR2>(a, n, rowBase, Hs, Gb, NR2 * rh, j, kq, wp, gStride, acc, [&]() {
       if (a.px) {
-        const float4* pf = reinterpret_cast<const float4*>(a.px) + ((((size_t)n * RB + rb) * 12 + 8 + ct) * 4 + 2 * rh) * 64 + lane;
-        pxv[0] = pf[0]; pxv[1] = pf[64];
-      } else {
-        pxv[0] = make_float4(0.f, 0.f, 0.f, 0.f); pxv[1] = pxv[0];
-        x_groups<2>(a, n, rowBase, 2 * rh, wp + (size_t)nG * gStride, gStride, j, kq, acc);
-      }
-      const float4* rf = reinterpret_cast<const float4*>(a.r) + ((((size_t)n * RB + rb) * 4 + ct) * 4 + 2 * rh) * 64 + lane;
-      rv[0] = rf[0]; rv[1] = rf[64];
+        const float4* pf = reinterpret_cast<const float4*>(a.px) +
+                           ((((size_t)n * RB + rb) * 12 + 8 + ct) * 4 + rtb + NR2 * rh) * 64 + lane;
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NR2; ++q) pxv[q] = pf[q * 64];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NR2; ++q) pxv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x_groups<NR2>(a, n, rowBase, NR2 * rh, wp + (size_t)nG * gStride, gStride, j, kq, acc);
+      }
+      const float4* rf = reinterpret_cast<const float4*>(a.r) + ((((size_t)n * RB + rb) * 4 + ct) * 4 + rtb + NR2 * rh) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < NR2; ++q) rv[q] = rf[q * 64];
+#pragma unroll
+      for (int q = 0; q < NR2; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int b = min(rowBase + (2 * rh + q) * 16 + 4 * kq + e, a.rows - 1);
+          const int b = min(rowBase + (NR2 * rh + q) * 16 + 4 * kq + e, a.rows - 1);
           hv[q][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
         }
     });
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NR2; ++q) {
       acc[q][0] += pxv[q].x; acc[q][1] += pxv[q].y; acc[q][2] += pxv[q].z; acc[q][3] += pxv[q].w;
     }
     __syncthreads();   // every wave is out of the K loop: Hs (z*h) may be overwritten by h'
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NR2; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int lb = (2 * rh + q) * 16 + 4 * kq + e, b = rowBase + lb;
+        const int lb = (NR2 * rh + q) * 16 + 4 * kq + e, b = rowBase + lb;
         const float hc = tanhf(acc[q][e]);
         const float rr = e == 0 ? rv[q].x : e == 1 ? rv[q].y : e == 2 ? rv[q].z : rv[q].w;
         float hn = rr * hv[q][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
@@ -519,12 +567,12 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
     if (MODE == 0) return;
   } else {
     // residual cell only: h' := s rows
-    float4 sv[2];
+    float4 sv[NS];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NS; ++it)
       sv[it] = *reinterpret_cast<const float4*>(a.s + ((size_t)min(rowBase + srow + 32 * it, a.rows - 1) * a.Np + n) * 64 + sq * 4);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NS; ++it) {
       const int rr = srow + 32 * it;
       *reinterpret_cast<float4*>(&Hs[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(rowBase + rr < a.rows, sv[it]);
     }
@@ -534,7 +582,7 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
   const int ngx = a.Cpad >> 4;                     // x groups of the residual GEMMs (1 or 4)
   const int nG1 = ngx + 4;                         // <= 8
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {   // x_t tile (zero padded to Cpad)
+  for (int it = 0; it < NS; ++it) {   // x_t tile (zero padded to Cpad)
     const int rr = srow + 32 * it;
     const bool ok = rowBase + rr < a.rows;
     const size_t xrow = (size_t)min(rowBase + rr, a.rows - 1) * a.xRowStride;
@@ -563,27 +611,27 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
   const float bg = a.rgb[16 * w + j], bu = a.rub[o4];
   const float gate = a.blend ? sigmoid16(a.blend[0]) : 0.f;   // g = sigmoid(weights_gru[l][t]) (:208)
   __syncthreads();
-  // GEMM 1: zr2 = sigmoid([x|h'] Wg + bg): wave w = column tile w (of 8), 4 row tiles
-  f32x4 acc1[4];
+  // GEMM 1: zr2 = sigmoid([x|h'] Wg + bg): wave w = column tile w (of 8), all row tiles
+  f32x4 acc1[NRT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < NRT; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     if (g < nG1) {
       const float* T = (g < ngx) ? XT : Hs;
       const int gg = (g < ngx) ? g : g - ngx;
       const float4 wv = rgv[g];
-      float4 av[4];
+      float4 av[NRT];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) av[rt] = *reinterpret_cast<const float4*>(&T[((rt * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
+      for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const float4*>(&T[((rt * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].x, wv.x, acc1[rt]);
+      for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].x, wv.x, acc1[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].y, wv.y, acc1[rt]);
+      for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].y, wv.y, acc1[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].z, wv.z, acc1[rt]);
+      for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].z, wv.z, acc1[rt]);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].w, wv.w, acc1[rt]);
+      for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].w, wv.w, acc1[rt]);
     }
   }
   // the weights of GEMM 2 are requested now (the registers of GEMM 1's weights are free): they land under the sigmoids
@@ -596,7 +644,7 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
   {
     const int o = 16 * w + j;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int lb = rt * 16 + 4 * kq + e;
@@ -608,39 +656,39 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
       }
   }
   __syncthreads();
-  // GEMM 2: hc2 = tanh([x | z2*h'] Wu + bu): wave (ct, rp) -> column tile ct, row tiles 2rp, 2rp+1
-  f32x4 acc2[2];
-  acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-  acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // GEMM 2: hc2 = tanh([x | z2*h'] Wu + bu): wave (ct, rp) -> column tile ct, the row tiles of half rp
+  f32x4 acc2[NR2];
+#pragma unroll
+  for (int q = 0; q < NR2; ++q) acc2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     if (g < nG1) {
       const float* T = (g < ngx) ? XT : ZH2;
       const int gg = (g < ngx) ? g : g - ngx;
       const float4 wv = ruv[g];
-      float4 av[2];
+      float4 av[NR2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        av[q] = *reinterpret_cast<const float4*>(&T[(((2 * rp + q) * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
+      for (int q = 0; q < NR2; ++q)
+        av[q] = *reinterpret_cast<const float4*>(&T[(((NR2 * rp + q) * 16 + j) * 16 + ((4 * gg + kq) ^ j)) * 4]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].x, wv.x, acc2[q]);
+      for (int q = 0; q < NR2; ++q) acc2[q] = MFMA16(av[q].x, wv.x, acc2[q]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].y, wv.y, acc2[q]);
+      for (int q = 0; q < NR2; ++q) acc2[q] = MFMA16(av[q].y, wv.y, acc2[q]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].z, wv.z, acc2[q]);
+      for (int q = 0; q < NR2; ++q) acc2[q] = MFMA16(av[q].z, wv.z, acc2[q]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc2[q] = MFMA16(av[q].w, wv.w, acc2[q]);
+      for (int q = 0; q < NR2; ++q) acc2[q] = MFMA16(av[q].w, wv.w, acc2[q]);
     }
   }
-  // the new state is gathered as a [64][64] tile in LDS (over x_t, dead once every wave has left GEMM 2) and
+  // the new state is gathered as a [ROWS][64] tile in LDS (over x_t, dead once every wave has left GEMM 2) and
   // written to the state and to Seq_l[t] as whole 256-byte rows
   __syncthreads();
   float* Out = XT;
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < NR2; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int lb = (2 * rp + q) * 16 + 4 * kq + e;
+      const int lb = (NR2 * rp + q) * 16 + 4 * kq + e;
       const float hc = tanhf(acc2[q][e] + bu);
       if (SAVE && rowBase + lb < a.rows) a.svHC2[((size_t)(rowBase + lb) * a.Np + n) * 64 + o4] = hc;
       const float hp = Hs[swz(lb, o4, 16)];
@@ -650,7 +698,7 @@ __global__ __launch_bounds__(512, NODE_MIN_WAVES) void k_update16(Node16Args a) 
     }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {                  // 64 rows x 16 slots = 1024 float4 over 512 threads
+  for (int it = 0; it < NS; ++it) {                 // ROWS rows x 16 slots float4 over 512 threads
     const int lb = srow + 32 * it, b = rowBase + lb;
     if (b >= a.rows) continue;
     const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (sq ^ (lb & 15))) * 4]);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--serial", action="store_true")
     ap.add_argument("--cache-prepared", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="per-kernel launch averages, wavefront off (HIP events)")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from multistgraph_amd import _lib, synthetic as syn
@@ -42,6 +43,11 @@ def main():
     ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
     line = "%-28s %s fwd median %.3f ms  p10 %.3f  p90 %.3f" % (args.tag, args.workload, statistics.median(ts),
                                                               ts[len(ts) // 10], ts[len(ts) * 9 // 10])
+    if args.kernels:
+        ser = bench.in_situ_kernel_times(model, batch, wavefront=False, forwards=2)
+        line += "   serial us/launch: " + "  ".join("%s %.1f (x%d)" % (k, 1e3 * statistics.mean(v), len(v) // 2)
+                                                    for k, v in sorted(ser.items()))
+        line += "   serial sum %.2f ms" % (sum(sum(v) for v in ser.values()) / 2)
     if args.train:
         t = bench.train_step_times(model, batch, w, warm=3, steps=8)
         line += "   train: fwd %.2f bwd %.2f step %.2f ms" % (t["forward_ms"], t["backward_ms"], t["ms_per_step"])
