@@ -1,7 +1,7 @@
 // LAB: how do the bits of a HIP stream's CU mask (hipExtStreamCreateWithCUMask) map onto the 8 XCDs of an MI355X, and
 // can two streams with disjoint masks run kernels side by side?  (Round 3: the two layers' recurrent chains phase-lock
 // when they share the chip - DESIGN.md section 4 - so giving each chain its own XCDs is worth a measurement.)
-//   hipcc -O3 --offload-arch=gfx950 tools/cumask_probe.hip -o tools/cumask_probe && tools/cumask_probe
+//   hipcc -O3 --offload-arch=gfx950 tools/labs/cumask_probe.hip -o tools/labs/cumask_probe && tools/labs/cumask_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

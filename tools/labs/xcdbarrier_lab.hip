@@ -6,7 +6,7 @@
 // word and acquires.  Monotonic counters (no reset race), relaxed sc1 polls with s_sleep, every spin BOUNDED.
 // Optional payload: every workgroup writes PAYLOAD_KB of plain stores before the barrier and reads the slab of the
 // workgroup 37 places further on after it (checked: a stale read is counted).
-//   hipcc -O3 --offload-arch=gfx950 tools/xcdbarrier_lab.hip -o tools/xcdbarrier_lab && tools/xcdbarrier_lab
+//   hipcc -O3 --offload-arch=gfx950 tools/labs/xcdbarrier_lab.hip -o tools/labs/xcdbarrier_lab && tools/labs/xcdbarrier_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
