@@ -2,7 +2,7 @@
 # round 3, lab b: do the chains gain from disjoint CU sets (MATGCN_CU_SPLIT)?  outputs under gpurun_out/r03lab_b/
 set -o pipefail
 out=gpurun_out/r03lab_b; mkdir -p $out
-timeout -k 10 120 tools/cumask_probe > $out/cumask_probe.log 2>&1
+timeout -k 10 120 tools/labs/cumask_probe > $out/cumask_probe.log 2>&1
 python tools/fwd_time.py --tag "default wavefront" > $out/times.log 2>&1 || exit 1
 for a in 8 12 14 16 18 20 24; do
   for x in 0 1; do
