@@ -39,6 +39,8 @@ struct Plan {
   // prepared offsets (floats)
   long oSt, oPlainA, oPlainB, oPlainC;
   long oWg[MATGCN_MAX_LAYERS], oWu[MATGCN_MAX_LAYERS], oWx[MATGCN_MAX_LAYERS], oBx[MATGCN_MAX_LAYERS];
+  long wgFloats[MATGCN_MAX_LAYERS], wuFloats[MATGCN_MAX_LAYERS];   // floats of the two recurrent weight streams
+  long oW16g[MATGCN_MAX_LAYERS], oW16u[MATGCN_MAX_LAYERS];         // workspace: their bf16 copies (precision mode 2)
   long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
   long wxStride;
   int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], nGx[MATGCN_MAX_LAYERS];
@@ -117,8 +119,9 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->Cpad[l] = (int)rup(P->Cl[l], 16);
     P->nGx[l] = (l == 0) ? P->Kx / 16 : 0;
     const long kt = P->gcnOff ? 0 : (long)P->Ktot * H + 16L * P->nGx[l];
-    P->oWg[l] = take((long)P->N * kt * 128);
-    P->oWu[l] = take((long)P->N * kt * 64);
+    P->wgFloats[l] = (long)P->N * kt * 128; P->wuFloats[l] = (long)P->N * kt * 64;
+    P->oWg[l] = take(P->wgFloats[l]);
+    P->oWu[l] = take(P->wuFloats[l]);
     if (l > 0 && !P->gcnOff) {
       P->wxStride = (long)P->Ktot * H * 192;
       P->oWx[l] = take((long)P->N * P->wxStride);
@@ -144,6 +147,8 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oG[l] = take((long)P->N * P->B * P->Ks * H);
     P->oR[l] = take((long)P->N * P->RB * NODE_R_BLOCK);
     P->oSeq[l] = take(rowsBT * P->Np * H);
+    P->oW16g[l] = take((P->wgFloats[l] + 1) / 2);   // bf16: two values per float slot
+    P->oW16u[l] = take((P->wuFloats[l] + 1) / 2);
     if (l > 0 && !P->gcnOff) {
       P->oGX[l] = take((long)P->T * P->N * P->B * P->Ks * H);   // every chunk keeps its own block [N][nt*B][Ks][64]
       P->oPX[l] = take((long)P->T * P->N * P->RB * NODE_PX_BLOCK);
@@ -324,11 +329,16 @@ inline Wavefront& wf_current() {
 }
 #define g_wf (wf_current())
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
-int g_mix_precision = 0;      // matgcn_set_mix_precision: 0 fp32 operands, 1 bf16 operands for the inference graph mixes
+int g_mix_precision = 0;      // matgcn_set_mix_precision: 0 fp32 operands, 1 bf16 operands for the inference graph mixes,
+                              // 2 bf16 operands for the graph mixes AND the node-wise contractions (bf16 weight streams)
 bool g_mix_bf16_now = false;  // set for the duration of an inference forward only (MixPrecisionScope)
+bool g_node_bf16_now = false;
 struct MixPrecisionScope {
-  explicit MixPrecisionScope(bool inferenceForward) { g_mix_bf16_now = inferenceForward && g_mix_precision == 1; }
-  ~MixPrecisionScope() { g_mix_bf16_now = false; }
+  explicit MixPrecisionScope(bool inferenceForward) {
+    g_mix_bf16_now = inferenceForward && g_mix_precision >= 1;
+    g_node_bf16_now = inferenceForward && g_mix_precision == 2;
+  }
+  ~MixPrecisionScope() { g_mix_bf16_now = false; g_node_bf16_now = false; }
 };
 
 int wavefront_ready() {
@@ -471,6 +481,8 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, NODE_ROWS>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false, NODE_ROWS>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, NODE_ROWS, true>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, NODE_ROWS, true>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -582,20 +594,24 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.svZ = c.train + c.R.oZ[l] + at; a.svR = c.train + c.R.oR[l] + at; a.svHC = c.train + c.R.oHC[l] + at;
     a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
   }
+  // precision mode 2 (inference forwards only): bf16 copies of the weight streams, made by encoder_chains
+  const bool bf = g_node_bf16_now && !save && res != nullptr && !raw;
   if (phase == 1) {
-    a.s = Hx; a.w = c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
+    a.s = Hx; a.w = bf ? c.ws + P.oW16g[l] : c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    if (save) hipLaunchKernelGGL((k_gate16<true, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
+    if (bf) hipLaunchKernelGGL((k_gate16<false, NODE_ROWS, true>), grid, dim3(512), GATE_LDS, s, a);
+    else if (save) hipLaunchKernelGGL((k_gate16<true, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     else hipLaunchKernelGGL((k_gate16<false, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     return launch_ok();
   }
-  a.s = ZHx; a.w = c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
+  a.s = ZHx; a.w = bf ? c.ws + P.oW16u[l] : c.prep + P.oWu[l]; a.r = R; a.h = Hx; a.hout = Hx;
   ProfScope prof(MATGCN_PROF_UPDATE, s);
   if (res) {
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
+    if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
+    else if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
     else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
     hipLaunchKernelGGL((k_update16<0, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
@@ -646,6 +662,19 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
   RETURN_IF(wavefront_ready());
   Wavefront& W = g_wf;
   const bool multi = P.L > 1 && g_wavefront_mode != 0;
+  if (g_node_bf16_now && !P.gcnOff && !c.train) {
+    // precision mode 2: bf16 copies of the recurrent weight streams into the workspace, once per forward and in front
+    // of the fork (every chain reads them); 240 MB of traffic, part of what the side line's time includes
+    for (int l = 0; l < P.L; ++l) {
+      const size_t og = (size_t)(P.wgFloats[l] / 8), ou = (size_t)(P.wuFloats[l] / 8);
+      hipLaunchKernelGGL(k_stream_to_bf16, dim3(blocks_for(og)), dim3(256), 0, c.s, c.prep + P.oWg[l],
+                         reinterpret_cast<unsigned int*>(c.ws + P.oW16g[l]), og);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_stream_to_bf16, dim3(blocks_for(ou)), dim3(256), 0, c.s, c.prep + P.oWu[l],
+                         reinterpret_cast<unsigned int*>(c.ws + P.oW16u[l]), ou);
+      CHECK_LAUNCH();
+    }
+  }
   if (multi) {
     HIP_OK(hipEventRecord(W.fork, c.s));
     for (int l = 1; l < P.L; ++l) {
@@ -910,7 +939,7 @@ int matgcn_series_violations(int64_t* count, int reset) {
 
 int matgcn_set_mix_precision(int mode) {
   const int prev = g_mix_precision;
-  g_mix_precision = mode == 1 ? 1 : 0;
+  g_mix_precision = (mode == 1 || mode == 2) ? mode : 0;
   return prev;
 }
 

@@ -113,6 +113,24 @@ __device__ __forceinline__ int swz(int row, int col, int spr) {
   return (row * spr + ((slot & ~15) | ((slot ^ row) & 15))) * 4 + (col & 3);
 }
 
+// ---- operand precision of the K loop ----------------------------------------------------------------------------
+// BF = false: fp32 operands on v_mfma_f32_16x16x4_f32 (the product path, bit-for-bit an fp32 fma chain).
+// BF = true (matgcn_set_mix_precision(2), inference only, a side line with its own tolerance): the node-adaptive weights
+// arrive as a bf16 copy of the same fragment stream - HALF the bytes of the one big stream of these kernels - and the A
+// rows are rounded to bf16 on their way into LDS; one v_mfma_f32_16x16x16_bf16 per k-group, fp32 accumulation.  A lane's
+// four bf16 of a k-group are exactly the four fp32 of its float4 in the fp32 stream (k = 16 g + 4 (l >> 4) + s), so both
+// streams share one indexing.  State, PX, R, the residual cell and every epilogue stay fp32.
+template <bool BF> struct NodeOp { typedef float4 T; };
+template <> struct NodeOp<true> { typedef uint2 T; };
+__device__ __forceinline__ uint2 to_bf16x4(const float4& v) {
+  return make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+}
+__device__ __forceinline__ bf16x4_t as_bf16x4(const uint2& v) {
+  bf16x4_t r;
+  r[0] = (short)(v.x & 0xffffu); r[1] = (short)(v.x >> 16); r[2] = (short)(v.y & 0xffffu); r[3] = (short)(v.y >> 16);
+  return r;
+}
+
 // ---- K-chunk pipeline shared by k_gate16 and k_update16 --------------------------------------------------------
 // staging coordinates of a thread: rows srow and srow + 32 of a chunk, 16-byte slot sq
 // a ROWS-row chunk is ROWS x 16 slots = ROWS/32 float4 per thread of the 512: sweep it of a thread is row srow + 32 it
@@ -150,12 +168,13 @@ __device__ __forceinline__ void chunk_load(const ChunkStage<ROWS>& c, int Ks, in
 }
 
 // registers -> one [ROWS][16 slots] swizzled LDS chunk; rows beyond a.rows are zero
-template <int ROWS>
+template <int ROWS, bool BF = false>
 __device__ __forceinline__ void chunk_store(float* buf, const ChunkStage<ROWS>& c, const float4 (&r)[ROWS / 32]) {
 #pragma unroll
   for (int it = 0; it < ROWS / 32; ++it) {
     const int rr = c.srow + 32 * it;
-    *reinterpret_cast<float4*>(&buf[(rr * 16 + (c.sq ^ (rr & 15))) * 4]) = keep4(c.v[it], r[it]);
+    if constexpr (BF) *reinterpret_cast<uint2*>(&buf[(rr * 16 + (c.sq ^ (rr & 15))) * 2]) = to_bf16x4(keep4(c.v[it], r[it]));
+    else *reinterpret_cast<float4*>(&buf[(rr * 16 + (c.sq ^ (rr & 15))) * 4]) = keep4(c.v[it], r[it]);
   }
 }
 
@@ -164,11 +183,13 @@ __device__ __forceinline__ void chunk_store(float* buf, const ChunkStage<ROWS>& 
 // MFMA (a refill of the half being read could only issue after the MFMAs that read it: round 2 measured exactly that
 // - the loads bunched up at the end of the chunk and the next chunk began by waiting for them).  A fragments come from
 // the LDS chunk; accumulators rotate so that a chain is revisited every NRT-th instruction.
-template <int NRT, int PAR, bool PREFETCH>
-__device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int kq, float4 (&wr)[2][4], const float4* wp,
-                                           size_t gStride, int gNext, int gLast, f32x4 (&acc)[NRT]) {
+template <int NRT, int PAR, bool PREFETCH, bool BF = false>
+__device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int kq, typename NodeOp<BF>::T (&wr)[2][4],
+                                           const typename NodeOp<BF>::T* wp, size_t gStride, int gNext, int gLast,
+                                           f32x4 (&acc)[NRT]) {
+  typedef typename NodeOp<BF>::T Op;
   if (PREFETCH) {
-#ifdef NODE_LAB_NO_WEIGHTS   // tools/nodelab2.hip: every k-group re-reads the node's first one (an L1 hit)
+#ifdef NODE_LAB_NO_WEIGHTS   // tools/labs/nodelab2.hip: every k-group re-reads the node's first one (an L1 hit)
     gNext = 0; gLast = 0;
 #endif
 #pragma unroll
@@ -176,26 +197,31 @@ __device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int
     // the scheduler would otherwise sink these loads below the chunk's MFMAs to shorten their live ranges
     __builtin_amdgcn_sched_barrier(0);
   }
+  const Op* tile = reinterpret_cast<const Op*>(buf);
 #pragma unroll
   for (int gl = 0; gl < 4; ++gl) {
-    float4 av[NRT];
+    Op av[NRT];
 #pragma unroll
-    for (int q = 0; q < NRT; ++q)
-      av[q] = *reinterpret_cast<const float4*>(&buf[(((rt0 + q) * 16 + j) * 16 + ((4 * gl + kq) ^ j)) * 4]);
-    const float4 wv = wr[PAR][gl];
-#ifdef NODE_LAB_NO_MFMA   // tools/nodelab2.hip: the same operand traffic without the matrix pipe
+    for (int q = 0; q < NRT; ++q) av[q] = tile[((rt0 + q) * 16 + j) * 16 + ((4 * gl + kq) ^ j)];
+    const Op wv = wr[PAR][gl];
+    if constexpr (BF) {
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q][0] += av[q].x * wv.x + av[q].y * wv.y + av[q].z * wv.z + av[q].w * wv.w;
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16BF(as_bf16x4(av[q]), as_bf16x4(wv), acc[q]);
+    } else {
+#ifdef NODE_LAB_NO_MFMA   // tools/labs/nodelab2.hip: the same operand traffic without the matrix pipe
+#pragma unroll
+      for (int q = 0; q < NRT; ++q) acc[q][0] += av[q].x * wv.x + av[q].y * wv.y + av[q].z * wv.z + av[q].w * wv.w;
 #else
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
 #endif
+    }
   }
 }
 
@@ -212,9 +238,10 @@ __device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int
 //              for c = 1..Ks-1:  request the weights of chunk c+1, chunk c from Gb[(c-1)&1];  barrier;
 //                                Gb[(c-1)&1] <- chunk c+2, request chunk c+4
 //              late();  chunk Ks
-template <int ROWS, int NRT, typename Late>
+template <int ROWS, int NRT, bool BF, typename Late>
 __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowBase, float* Hs, float* Gb, int rt0, int j,
-                                            int kq, const float4* wp, size_t gStride, f32x4 (&acc)[NRT], Late&& late) {
+                                            int kq, const typename NodeOp<BF>::T* wp, size_t gStride, f32x4 (&acc)[NRT],
+                                            Late&& late) {
   constexpr int NS = ROWS / 32, CH = ROWS * 64;      // float4 per thread and chunk; floats of one LDS chunk
   const int Ks = a.Ks, gLast = 4 * (1 + Ks) - 1;
   const ChunkStage<ROWS> cs = chunk_stage<ROWS>(a, n, rowBase);
@@ -222,7 +249,7 @@ __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowB
 #pragma unroll
   for (int it = 0; it < NS; ++it)
     hS[it] = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.g[it] * a.Np + n) * 64 + cs.sq * 4);
-  float4 wr[2][4];       // weight ring: chunk c reads half c & 1
+  typename NodeOp<BF>::T wr[2][4];       // weight ring: chunk c reads half c & 1
 #pragma unroll
   for (int r = 0; r < 4; ++r) wr[0][r] = wp[(size_t)min(r, gLast) * gStride];
   // staging registers: chunk c waits in st[c & 1].  Every request below is UNCONDITIONAL (the chunk index is clamped, a
@@ -233,55 +260,60 @@ __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowB
   chunk_load<ROWS>(cs, Ks, 2, st[0]);
 #pragma unroll
   for (int q = 0; q < NRT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  chunk_store<ROWS>(Hs, cs, hS);
+  chunk_store<ROWS, BF>(Hs, cs, hS);
   __syncthreads();
   if (Ks > 0) {
-    chunk_mfma<NRT, 0, true>(Hs, rt0, j, kq, wr, wp, gStride, 4, gLast, acc);
-    chunk_store<ROWS>(Gb, cs, st[1]);
-    if (Ks > 1) chunk_store<ROWS>(Gb + CH, cs, st[0]);
+    chunk_mfma<NRT, 0, true, BF>(Hs, rt0, j, kq, wr, wp, gStride, 4, gLast, acc);
+    chunk_store<ROWS, BF>(Gb, cs, st[1]);
+    if (Ks > 1) chunk_store<ROWS, BF>(Gb + CH, cs, st[0]);
     chunk_load<ROWS>(cs, Ks, 3, st[1]);
     chunk_load<ROWS>(cs, Ks, 4, st[0]);
     __syncthreads();
     for (int c = 1; c < Ks; c += 2) {
       // odd chunk c (not the last) in Gb[0]; afterwards Gb[0] <- chunk c+2 (waiting in st[1])
-      chunk_mfma<NRT, 1, true>(Gb, rt0, j, kq, wr, wp, gStride, 4 * (c + 1), gLast, acc);
+      chunk_mfma<NRT, 1, true, BF>(Gb, rt0, j, kq, wr, wp, gStride, 4 * (c + 1), gLast, acc);
       __syncthreads();
-      if (c + 2 <= Ks) chunk_store<ROWS>(Gb, cs, st[1]);
+      if (c + 2 <= Ks) chunk_store<ROWS, BF>(Gb, cs, st[1]);
       chunk_load<ROWS>(cs, Ks, c + 4, st[1]);
       if (c + 1 < Ks) {  // even chunk c+1 (not the last) in Gb[1]; afterwards Gb[1] <- chunk c+3 (waiting in st[0])
-        chunk_mfma<NRT, 0, true>(Gb + CH, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
+        chunk_mfma<NRT, 0, true, BF>(Gb + CH, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
         __syncthreads();
-        if (c + 3 <= Ks) chunk_store<ROWS>(Gb + CH, cs, st[0]);
+        if (c + 3 <= Ks) chunk_store<ROWS, BF>(Gb + CH, cs, st[0]);
         chunk_load<ROWS>(cs, Ks, c + 5, st[0]);
       }
     }
   }
   late();
-  if (Ks & 1) chunk_mfma<NRT, 1, false>(Gb, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);               // odd last chunk
-  else chunk_mfma<NRT, 0, false>(Ks > 0 ? Gb + CH : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
+  if (Ks & 1) chunk_mfma<NRT, 1, false, BF>(Gb, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);               // odd last chunk
+  else chunk_mfma<NRT, 0, false, BF>(Ks > 0 ? Gb + CH : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
 }
 
 // layer-0 x part: acc[q] += XA[rows of tile rt0+q][16 gx .. +16] . Wx[gx]; A fragments come straight from global
 // memory (a row of XA is 64*nGx bytes, a 16-row tile is contiguous), weights from the tail of the node's stream
-template <int NRT>
-__device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, int rt0, const float4* wx, size_t gStride,
-                                         int i, int kq, f32x4 (&acc)[NRT]) {
+template <int NRT, bool BF = false>
+__device__ __forceinline__ void x_groups(const Node16Args& a, int n, int rowBase, int rt0, const typename NodeOp<BF>::T* wx,
+                                         size_t gStride, int i, int kq, f32x4 (&acc)[NRT]) {
   const int kx = 16 * a.nGx;
   const float* base = a.xa + (size_t)n * a.rows * kx + kq * 4;
   for (int gx = 0; gx < a.nGx; ++gx) {
-    const float4 wv = wx[(size_t)gx * gStride];
+    const typename NodeOp<BF>::T wv = wx[(size_t)gx * gStride];
     float4 av[NRT];
 #pragma unroll
     for (int q = 0; q < NRT; ++q)
       av[q] = *reinterpret_cast<const float4*>(base + (size_t)min(rowBase + (rt0 + q) * 16 + i, a.rows - 1) * kx + gx * 16);
+    if constexpr (BF) {
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16BF(as_bf16x4(to_bf16x4(av[q])), as_bf16x4(wv), acc[q]);
+    } else {
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].x, wv.x, acc[q]);
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].y, wv.y, acc[q]);
 #pragma unroll
-    for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].z, wv.z, acc[q]);
+#pragma unroll
+      for (int q = 0; q < NRT; ++q) acc[q] = MFMA16(av[q].w, wv.w, acc[q]);
+    }
   }
 }
 
@@ -300,8 +332,9 @@ inline unsigned node_items(int N, int rows, int blockRows) {
 
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
 // wave w = column tile w of 8 (0..3: z, 4..7: r), all ROWS/16 row tiles.  LDS 3 chunks of ROWS x 64 floats: Hs | Gb[2]
-template <bool SAVE, int ROWS>
+template <bool SAVE, int ROWS, bool BF = false>
 __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_32) void k_gate16(Node16Args a) {
+  typedef typename NodeOp<BF>::T Op;
   constexpr int NRT = ROWS / 16, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;               // [ROWS][16 slots] the state rows: chunk 0, and the h of z*h
@@ -313,10 +346,20 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + a.Ks);
   const size_t gStride = 8 * 64;
-  const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
+  const Op* wp = reinterpret_cast<const Op*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
   f32x4 acc[NRT];
   float4 pxv[NRT];               // hoisted pre-activation (x rows + bias) in fragment order, added in the epilogue
-  node_k_loop<ROWS, NRT>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
+  float hz[BF ? NRT : 1][4];     // BF: the fp32 state values of z*h (the LDS copy is rounded to bf16), requested late
+  node_k_loop<ROWS, NRT, BF>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
+    if constexpr (BF) {
+      if (w < 4) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            hz[rt][e] = a.s[((size_t)min(rowBase + rt * 16 + 4 * kq + e, a.rows - 1) * a.Np + n) * 64 + 16 * w + j];
+      }
+    }
     if (a.px) {
       const float4* pf = reinterpret_cast<const float4*>(a.px) + ((((size_t)n * RB + rb) * 12 + w) * 4 + rtb) * 64 + lane;
 #pragma unroll
@@ -324,7 +367,7 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     } else {   // layer 0 contracts its narrow x part here, straight from global memory
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) pxv[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      x_groups<NRT>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
+      x_groups<NRT, BF>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
     }
   });
 #pragma unroll
@@ -346,8 +389,12 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
       if (a.raw && b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
       const float sg = sigmoid16(v);
       if (SAVE && b < a.rows) ((w < 4) ? a.svZ : a.svR)[((size_t)b * a.Np + n) * 64 + (o & 63)] = sg;
-      if (w < 4) Out[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
-      else acc[rt][e] = sg;
+      if (w < 4) {
+        if constexpr (BF) Out[swz(lb, o, 16)] = sg * hz[rt][e];
+        else Out[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
+      } else {
+        acc[rt][e] = sg;
+      }
     }
   }
   if (w >= 4) {
@@ -497,8 +544,9 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
 // two waves of a column tile request the same weight fragments: the second request is an L1 / L2 hit, HBM sees each
 // byte once).  The residual cell then runs two small GEMMs on tiles that never leave LDS.
 // LDS 4 chunks of ROWS x 64 floats: Hs | Gb[2] | X
-template <int MODE, bool SAVE, int ROWS>
+template <int MODE, bool SAVE, int ROWS, bool BF = false>
 __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_32) void k_update16(Node16Args a) {
+  typedef typename NodeOp<BF>::T Op;
   constexpr int NRT = ROWS / 16, NR2 = ROWS / 32, NS = ROWS / 32, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;               // [ROWS][16 slots]: z*h (chunk 0) during the update GEMM, then h'
@@ -518,13 +566,13 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
   if (MODE != 2) {
     const int nG = 4 * (1 + a.Ks);
     const size_t gStride = 4 * 64;
-    const float4* wp = reinterpret_cast<const float4*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
+    const Op* wp = reinterpret_cast<const Op*>(a.w) + ((size_t)n * (nG + a.nGx) * 4 + ct) * 64 + lane;
     f32x4 acc[NR2];
     // epilogue operands, requested just before the last chunk: PX and r in fragment order (r as k_gate16 left it),
     // the previous state row-major
     float4 pxv[NR2], rv[NR2];
     float hv[NR2][4];
-    node_k_loop<ROWS, NR2>(a, n, rowBase, Hs, Gb, NR2 * rh, j, kq, wp, gStride, acc, [&]() {
+    node_k_loop<ROWS, NR2, BF>(a, n, rowBase, Hs, Gb, NR2 * rh, j, kq, wp, gStride, acc, [&]() {
       if (a.px) {
         const float4* pf = reinterpret_cast<const float4*>(a.px) +
                            ((((size_t)n * RB + rb) * 12 + 8 + ct) * 4 + rtb + NR2 * rh) * 64 + lane;
@@ -533,7 +581,7 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
       } else {
 #pragma unroll
         for (int q = 0; q < NR2; ++q) pxv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        x_groups<NR2>(a, n, rowBase, NR2 * rh, wp + (size_t)nG * gStride, gStride, j, kq, acc);
+        x_groups<NR2, BF>(a, n, rowBase, NR2 * rh, wp + (size_t)nG * gStride, gStride, j, kq, acc);
       }
       const float4* rf = reinterpret_cast<const float4*>(a.r) + ((((size_t)n * RB + rb) * 4 + ct) * 4 + rtb + NR2 * rh) * 64 + lane;
 #pragma unroll
@@ -705,6 +753,16 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     store_wt16(a.hout, ((size_t)b * a.Np + n) * 64 + sq * 4, v);
     if (a.seq) store_wt16(a.seq, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4, v);
   }
+}
+
+// bf16 copy of a fragment-ordered weight stream (same indexing, half the bytes): 8 floats per thread
+__global__ __launch_bounds__(256) void k_stream_to_bf16(const float* __restrict__ src, unsigned int* __restrict__ dst,
+                                                        size_t octets) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= octets) return;
+  const float4 v0 = *reinterpret_cast<const float4*>(src + i * 8), v1 = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+  const uint2 p0 = to_bf16x4(v0), p1 = to_bf16x4(v1);
+  *reinterpret_cast<uint4*>(dst + i * 4) = make_uint4(p0.x, p0.y, p1.x, p1.y);
 }
 
 // ---- parameter-only: the node-adaptive weight streams are written by k_prep_stream (matgcn_kernels.hip) ----

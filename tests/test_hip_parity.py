@@ -178,9 +178,10 @@ def test_forward(name, fold, lib_built):
 BF16_TOL = 5e-3
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_od_non_c3", "tiny_multi_uni_c1", "tiny_multi_uni_c2_static",
-                                  "dc237_out12", "bm403_out24"])
-def test_bf16_mix_variant(name, lib_built):
+                                  "tiny_heads_331", "tiny_multi_uni_dyn7", "dc237_out12", "bm403_out24"])
+def test_bf16_mix_variant(name, mode, lib_built):
     """BASELINE config 3's dtype as an opt-in side line (matgcn_set_mix_precision(1)): bf16 OPERANDS for the graph
     mixes, fp32 accumulation, fp32 state and node-wise contractions.  Narrower than the reference's fp32, so it has
     its own tolerance: 5e-3 max-normalised against the reference's fp32 prediction (measured <= 3e-3); the fp32 path
@@ -191,9 +192,12 @@ def test_bf16_mix_variant(name, lib_built):
     h0 = c.h0()
     h0 = None if h0 is None else h0.to(dev)
     exact = hp.forward(x, h0).clone()
-    prev = hp.lib.matgcn_set_mix_precision(1)
+    prev = hp.lib.matgcn_set_mix_precision(mode)
     try:
         got = hp.forward(x, h0).clone()
+        if mode == 2:
+            hp.lib.matgcn_set_mix_precision(1)
+            assert not torch.equal(hp.forward(x, h0), got)          # mode 2 is more than mode 1
     finally:
         hp.lib.matgcn_set_mix_precision(prev)
     assert not torch.equal(got, exact)                              # the variant really ran
