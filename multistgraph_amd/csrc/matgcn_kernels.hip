@@ -467,6 +467,9 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1, j = lane & 15, kq = lane >> 4;
   const int kk = tid >> 4, sg = tid & 15;
+#ifdef MIX_LAB_STAGGER   // LAB: the workgroups that share a CU (ids 256 apart) start MIX_LAB_STAGGER x 64 cycles apart
+  for (int d = 0; d < (int)(blockIdx.x >> 8); ++d) __builtin_amdgcn_s_sleep(MIX_LAB_STAGGER);
+#endif
   const int part = blockIdx.y;     // split reduction (MixArgs.parts): 0 unless the launch has a second grid dimension
   const float* ap = a.St + (size_t)part * a.aPartStride + (size_t)kk * a.ldS + row0 + sg * 4;
   const float* bp = a.X + (size_t)part * a.xPartStride + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
@@ -508,13 +511,18 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
       acc[1][1] = MFMA16(a1, b1, acc[1][1]);
     }
   };
-  for (int it = 0; it < a.nK; it += 2) {
+#ifdef MIX_LAB_NK   // LAB: only the first MIX_LAB_NK K-tiles (results are garbage: timing of the fixed part only)
+  const int nKrun = a.nK < MIX_LAB_NK ? a.nK : MIX_LAB_NK;
+#else
+  const int nKrun = a.nK;
+#endif
+  for (int it = 0; it < nKrun; it += 2) {
     mma(0);                                               // tile it
     *reinterpret_cast<float4*>(&As[1][stPos]) = ra0;      // tile it+1 (a clamped copy past the end: unused)
     *reinterpret_cast<float4*>(&Bs[1][stPos]) = rb0;
     ra0 = ldA(it + 3); rb0 = ldB(it + 3);
     __syncthreads();
-    if (it + 1 < a.nK) {
+    if (it + 1 < nKrun) {
       mma(1);                                             // tile it+1
       *reinterpret_cast<float4*>(&As[0][stPos]) = ra1;    // tile it+2
       *reinterpret_cast<float4*>(&Bs[0][stPos]) = rb1;
@@ -546,7 +554,11 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
     const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
     const int row = row0 + wr * 32 + lrow;
     const int k = row / a.Np, n = row - k * a.Np;
+#ifdef MIX_LAB_NOSTORE   // LAB: no output (a never-true condition keeps the accumulators alive)
+    if (k < a.Ks && n < a.N && v.x == 1.2345e-30f) {
+#else
     if (k < a.Ks && n < a.N) {
+#endif
       const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
       if (wt) {
         const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
