@@ -127,20 +127,25 @@ def step_kernel_models(n, npad, b, ks, h=64):
     }
 
 
-PMC_KERNEL_NAMES = {"k_mix": "k_mix<1>", "k_gate": "k_gate16<false>", "k_update": "k_update16<1, false>", "k_px": "k_px16"}
+# prefixes of the kernel names as rocprofv3 prints them (template arguments after these vary with the build)
+PMC_KERNEL_NAMES = {"k_mix": "k_mix<1>", "k_gate": "k_gate16<false", "k_update": "k_update16<1, false", "k_px": "k_px16"}
 
 
 def load_pmc(build_id):
-    """profiles/r02_pmc_kernels.json (tools/profile_r02.sh + tools/summarise_pmc.py) when it belongs to this build"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
-    if not os.path.exists(path):
+    """the newest profiles/r*_pmc_kernels.json (tools/profile_r03.sh + tools/summarise_pmc.py) that was collected on
+    THIS build (`build_id`, a hash of the library's sources); PMC figures of another build are never replayed"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")), reverse=True)
+    if not found:
         return None, "no PMC summary under profiles/"
-    with open(path) as fh:
-        doc = json.load(fh)
-    if doc.get("build_id") != build_id:
-        return None, "profiles/r02_pmc_kernels.json was collected on build %s, this is build %s: not replayed" % (
-            doc.get("build_id"), build_id)
-    return doc, "profiles/r02_pmc_kernels.json (build %s): %s" % (build_id, doc.get("method", "").split("\n")[0])
+    seen = []
+    for path in found:
+        with open(path) as fh:
+            doc = json.load(fh)
+        if doc.get("build_id") == build_id:
+            return doc, "%s (build %s): %s" % (os.path.relpath(path, ROOT), build_id, doc.get("method", "").split("\n")[0])
+        seen.append("%s=%s" % (os.path.basename(path), doc.get("build_id")))
+    return None, "no PMC summary of build %s under profiles/ (%s): not replayed" % (build_id, ", ".join(seen[:3]))
 
 
 def build_model(w, device, seed):

@@ -1,17 +1,17 @@
 #!/bin/bash
 # everything the round's evidence consists of, on one build: full GPU suite, smoke, profiler passes, bench lines
 set -o pipefail
-TAG=${1:-r02final}
+TAG=${1:-r03final}
 O=gpurun_out/$TAG
 mkdir -p $O
 python -m pytest tests -q -m gpu > $O/pytest.log 2>&1
 echo "pytest rc=$?"; tail -3 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo "smoke rc=$?"; tail -2 $O/smoke.log
-bash tools/profile_r02.sh $TAG > $O/profile.log 2>&1
+bash tools/profile_r03.sh $TAG > $O/profile.log 2>&1
 echo "profile rc=$?"; cat gpurun_out/prof_$TAG/pmc_kernels.txt
-cp gpurun_out/prof_$TAG/pmc_kernels.json profiles/r02_pmc_kernels.json
-bash tools/pmc_train_r02.sh $TAG > $O/pmc_train.log 2>&1
+cp gpurun_out/prof_$TAG/pmc_kernels.json profiles/r03_pmc_kernels.json
+bash tools/pmc_train_r03.sh $TAG > $O/pmc_train.log 2>&1
 echo "pmc train rc=$?"; head -24 gpurun_out/pmc_train_$TAG/train_pmc_kernels.txt
 bash tools/profile_train.sh $TAG > $O/profile_train.log 2>&1
 echo "profile train rc=$?"
