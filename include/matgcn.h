@@ -340,6 +340,15 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
  * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting. */
 int matgcn_set_wavefront(int enabled);
 
+/* matgcn_set_batch_split(2): the inference forwards (matgcn_forward, matgcn_forward_series) run the two halves of an
+ * even batch as two independent forwards of B / 2 samples side by side - half 0 on the caller's stream, half 1 on a
+ * library stream, each with its own layer wavefront and its own half of the workspace - and join them before the call's
+ * last event.  The samples of a batch never interact (MultiATGCN.py:363-420), so the result is that of two forwards of
+ * B / 2: the same kernels, the same arithmetic per sample.  Needs the wavefront on, fp32 operands and a workspace that
+ * holds two B / 2 plans (matgcn_workspace_bytes of the full batch does); otherwise the plain forward runs.  0 / 1: off
+ * (default).  Returns the previous setting. */
+int matgcn_set_batch_split(int parts);
+
 /* ---- precision option (BASELINE config 3's dtype; a side line, never the headline) -----------------------------
  * matgcn_set_mix_precision(1): the graph mixes of matgcn_forward / matgcn_forward_series round their operands - the
  * support stack and the state rows - to bf16 on the way into LDS and run on v_mfma_f32_16x16x16_bf16 with fp32

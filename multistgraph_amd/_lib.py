@@ -112,6 +112,7 @@ _SIGNATURES = {
     "matgcn_debug_gemm": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_float, C.c_float, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_set_mix_precision": (C.c_int, [C.c_int]),
+    "matgcn_set_batch_split": (C.c_int, [C.c_int]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "matgcn_profile_disable": (C.c_int, []),

@@ -321,12 +321,22 @@ struct Wavefront {
 // process that drives several GPUs (or the rehearsal runs that put two ranks on one box) must not share them.
 // (One host thread per device at a time, like the rest of the library: the reference is single-threaded too.)
 constexpr int MAX_DEVICES = 64;
-Wavefront g_wfs[MAX_DEVICES];
+// Two sets per device: the batch-split forward (matgcn_set_batch_split) runs the two halves of the batch as two
+// independent forwards side by side, each with its own layer wavefront; g_wf_set says which set the code below sees.
+Wavefront g_wfs[MAX_DEVICES][2];
+int g_wf_set = 0;
 inline Wavefront& wf_current() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
-  return g_wfs[dev];
+  return g_wfs[dev][g_wf_set];
 }
+struct SplitStreams {            // the second half's "caller stream" and the fork / join events around it
+  bool ready = false;
+  hipStream_t s1;
+  hipEvent_t fork, done;
+};
+SplitStreams g_split[MAX_DEVICES];
+int g_batch_split = 0;          // matgcn_set_batch_split: 0 / 1 off, 2 = two halves
 #define g_wf (wf_current())
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
 int g_mix_precision = 0;      // matgcn_set_mix_precision: 0 fp32 operands, 1 bf16 operands for the inference graph mixes,
@@ -340,6 +350,18 @@ struct MixPrecisionScope {
   }
   ~MixPrecisionScope() { g_mix_bf16_now = false; g_node_bf16_now = false; }
 };
+
+int split_ready() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  SplitStreams& S = g_split[dev];
+  if (S.ready) return MATGCN_OK;
+  HIP_OK(hipStreamCreateWithFlags(&S.s1, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+  S.ready = true;
+  return MATGCN_OK;
+}
 
 int wavefront_ready() {
   if (g_wf.ready) return MATGCN_OK;
@@ -376,8 +398,17 @@ int wavefront_ready() {
 // the caller with those streams still writing into the caller's buffers (workspace, train buffer, gradient bucket - the
 // caller may free or reuse them as soon as ITS stream is idle).  Whatever is in flight on every library stream is joined
 // into the caller's stream; the error code of the failed stage is what the call returns.
+void join_one_set(Wavefront& W, hipStream_t caller);
 void join_library_streams(hipStream_t caller) {
-  Wavefront& W = g_wf;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  for (int set = 0; set < 2; ++set) join_one_set(g_wfs[dev][set], caller);
+  if (g_split[dev].ready && g_split[dev].s1 != caller &&
+      hipEventRecord(g_split[dev].done, g_split[dev].s1) == hipSuccess)
+    (void)hipStreamWaitEvent(caller, g_split[dev].done, 0);
+  (void)hipGetLastError();
+}
+void join_one_set(Wavefront& W, hipStream_t caller) {
   if (!W.ready) return;
   hipStream_t all[2 * MATGCN_MAX_LAYERS + 3];
   int n = 0;
@@ -461,6 +492,8 @@ struct Ctx {
   hipStream_t s;
   float* train = nullptr;     // matgcn_forward_train: the training buffer (activations are saved into it)
   TrainPlan R;
+  size_t h0LayerStride = 0;   // floats between the layers of the caller's h0 (0: B*N*H; the batch-split halves see the
+                              // caller's full-batch layout)
 };
 
 // dynamic LDS: k_gate16 48 KB (state chunk + two ping-pong chunks), k_update16 64 KB (+ the x_t tile of the residual
@@ -483,6 +516,9 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true, NODE_ROWS>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, NODE_ROWS, true>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, NODE_ROWS, true>), at, UPDATE_LDS));
+  // 32-row work items for batches of at most 32 rows (the halves of the batch-split forward)
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, 32>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, 32>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
@@ -587,8 +623,11 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   a.g = G; a.gNodeStride = phase == 1 ? gNodeStride : 0; a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks;
   if (l == 0) { a.xa = c.ws + P.oXA0 + (size_t)t * P.N * P.B * P.Kx; a.nGx = P.nGx[0]; }
   else a.px = c.ws + P.oPX[l] + (size_t)t * P.N * P.RB * NODE_PX_BLOCK;
-  const dim3 grid(node_items(P.N, P.B, NODE_ROWS));   // (node, NODE_ROWS-row block) work items, XCD-paired per node
   const bool save = c.train != nullptr && res != nullptr;
+  // a batch of at most 32 rows (the halves of the batch-split forward) runs the 32-row instantiations: a 64-row tile
+  // would be half padding
+  const bool rows32 = NODE_ROWS == 64 && P.B <= 32 && !save && res != nullptr && !raw && !g_node_bf16_now;
+  const dim3 grid(node_items(P.N, P.B, rows32 ? 32 : NODE_ROWS));   // (node, row block) work items, XCD-paired per node
   if (save) {
     const size_t at = (size_t)t * P.B * P.Np * H;
     a.svZ = c.train + c.R.oZ[l] + at; a.svR = c.train + c.R.oR[l] + at; a.svHC = c.train + c.R.oHC[l] + at;
@@ -599,7 +638,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   if (phase == 1) {
     a.s = Hx; a.w = bf ? c.ws + P.oW16g[l] : c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    if (bf) hipLaunchKernelGGL((k_gate16<false, NODE_ROWS, true>), grid, dim3(512), GATE_LDS, s, a);
+    if (rows32) hipLaunchKernelGGL((k_gate16<false, 32>), grid, dim3(512), GATE_LDS / 2, s, a);
+    else if (bf) hipLaunchKernelGGL((k_gate16<false, NODE_ROWS, true>), grid, dim3(512), GATE_LDS, s, a);
     else if (save) hipLaunchKernelGGL((k_gate16<true, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     else hipLaunchKernelGGL((k_gate16<false, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     return launch_ok();
@@ -610,7 +650,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
+    if (rows32) hipLaunchKernelGGL((k_update16<1, false, 32>), grid, dim3(512), UPDATE_LDS / 2, s, a);
+    else if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
     else if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
     else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
@@ -693,7 +734,8 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
       CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, cs,
-                       h0User ? h0User + (size_t)l * P.B * P.N * H : nullptr, c.ws + P.oHx[l], P.B, P.N, P.Np, H);
+                       h0User ? h0User + (size_t)l * (c.h0LayerStride ? c.h0LayerStride : (size_t)P.B * P.N * H) : nullptr,
+                       c.ws + P.oHx[l], P.B, P.N, P.Np, H);
     CHECK_LAUNCH();
     if (c.train && h0User) {   // the backward needs h_{-1} of every layer (gate algebra, weight gradients of step 0)
       hipLaunchKernelGGL(k_pack_rows, dim3(blocks_for((size_t)P.B * P.Np * H)), dim3(256), 0, cs,
@@ -924,6 +966,12 @@ int matgcn_metric_table(const double* sums, int out_steps, int swap_r2, double* 
   return launch_ok();
 }
 
+int matgcn_set_batch_split(int parts) {
+  const int prev = g_batch_split;
+  g_batch_split = parts == 2 ? 2 : 0;
+  return prev;
+}
+
 int matgcn_series_violations(int64_t* count, int reset) {
   if (!count) return MATGCN_ERR_NULL;
   unsigned long long v = 0;
@@ -973,7 +1021,15 @@ int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes) {
   if (!bytes) return MATGCN_ERR_NULL;
   Plan P;
   RETURN_IF(make_plan(dims, &P));
-  *bytes = (size_t)P.workspaceFloats * sizeof(float);
+  size_t need = (size_t)P.workspaceFloats * sizeof(float);
+  if (dims->batch >= 2 && !(dims->batch & 1)) {     // room for the two half-batch plans of the batch-split forward
+    matgcn_dims half = *dims;
+    half.batch = dims->batch / 2;
+    Plan Q;
+    if (make_plan(&half, &Q) == MATGCN_OK && 2 * (size_t)Q.workspaceFloats * sizeof(float) > need)
+      need = 2 * (size_t)Q.workspaceFloats * sizeof(float);
+  }
+  *bytes = need;
   return MATGCN_OK;
 }
 
@@ -1131,6 +1187,67 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   return MATGCN_OK;
 }
 
+// one whole inference forward of `dims->batch` samples on stream c.s with the current wavefront set: head fusion
+// (from windows X, or - series != null - gathered from the resident series), encoder, head
+static int forward_once(Ctx& c, const float* X, const float* series, int64_t seriesSteps, const int32_t* labelStart,
+                        const int32_t* relSteps, const float* h0, float* out) {
+  const Plan& P = c.P;
+  float* x0p = c.ws + P.oX0p;
+  if (series) RETURN_IF(fuse_padded(c, series, x0p, labelStart, relSteps, seriesSteps));
+  else RETURN_IF(fuse_padded(c, X, x0p));
+  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
+  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+}
+
+// The batch-split forward (matgcn_set_batch_split(2)): the two halves of the batch are two independent forwards of
+// B / 2 samples - no arithmetic ties them, MultiATGCN.py:363-420 is per sample - run side by side: half 0 on the caller's
+// stream with wavefront set 0, half 1 on a library stream with set 1, each in its own half of the workspace, joined at
+// the end.  Four chains of half-size kernels instead of two: their fixed launch costs hide behind each other's work and
+// their smaller grids leave room to co-reside.  Same kernels, same per-sample arithmetic - the
+// results are those of two forwards of B / 2.
+static int forward_split(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                         const float* series, int64_t seriesSteps, const int32_t* labelStart, const int32_t* relSteps,
+                         const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream,
+                         bool* done) {
+  *done = false;
+  if (g_batch_split != 2 || g_wavefront_mode == 0 || g_mix_precision != 0 || dims->batch < 2 || (dims->batch & 1))
+    return MATGCN_OK;
+  matgcn_dims half = *dims;
+  half.batch = dims->batch / 2;
+  Ctx c0, c1;
+  Plan probe;
+  RETURN_IF(make_plan(&half, &probe));
+  const size_t halfBytes = (size_t)probe.workspaceFloats * sizeof(float);
+  if (2 * halfBytes > workspace_bytes) return MATGCN_OK;          // does not fit: the caller runs the plain forward
+  RETURN_IF(split_ready());
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  SplitStreams& S = g_split[dev];
+  RETURN_IF(make_ctx(&c0, &half, params, prepared, workspace, halfBytes, stream));
+  RETURN_IF(make_ctx(&c1, &half, params, prepared, (char*)workspace + halfBytes, halfBytes, S.s1));
+  const size_t layerStride = (size_t)dims->batch * dims->nodes * H;
+  c0.h0LayerStride = c1.h0LayerStride = layerStride;
+  const int hb = half.batch;
+  const size_t xHalf = (size_t)hb * dims->x_steps * dims->nodes * dims->x_feat;
+  const size_t outHalf = (size_t)hb * dims->out_channels * dims->nodes;
+  const size_t h0Half = (size_t)hb * dims->nodes * H;
+  HIP_OK(hipEventRecord(S.fork, c0.s));
+  HIP_OK(hipStreamWaitEvent(S.s1, S.fork, 0));
+  g_wf_set = 0;
+  int rc = forward_once(c0, X, series, seriesSteps, labelStart, relSteps, h0, out);
+  if (rc == MATGCN_OK) {
+    g_wf_set = 1;
+    rc = forward_once(c1, X ? X + xHalf : nullptr, series, seriesSteps, labelStart ? labelStart + hb : nullptr, relSteps,
+                      h0 ? h0 + h0Half : nullptr, out + outHalf);
+  }
+  g_wf_set = 0;
+  if (rc != MATGCN_OK) { join_library_streams(c0.s); return rc; }
+  HIP_OK(hipEventRecord(S.done, S.s1));
+  HIP_OK(hipStreamWaitEvent(c0.s, S.done, 0));
+  *done = true;
+  return MATGCN_OK;
+}
+
 int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
                    const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared || !X || !out) return MATGCN_ERR_NULL;
@@ -1139,12 +1256,12 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));
-  const Plan& P = c.P;
-  float* x0p = c.ws + P.oX0p;
+  bool done = false;
+  RETURN_IF(forward_split(dims, params, prepared, X, nullptr, 0, nullptr, nullptr, h0, out, workspace, workspace_bytes,
+                          stream, &done));
+  if (done) return MATGCN_OK;
   MixPrecisionScope mixScope(true);
-  RETURN_IF(fuse_padded(c, X, x0p));
-  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
-  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+  return forward_once(c, X, nullptr, 0, nullptr, nullptr, h0, out);
 }
 
 // the host-visible part of the series range contract: no window row may start before the series
@@ -1169,12 +1286,12 @@ int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, 
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));
   RETURN_IF(check_series(dims, series, series_steps, label_start, rel_steps));
-  const Plan& P = c.P;
-  float* x0p = c.ws + P.oX0p;
+  bool done = false;
+  RETURN_IF(forward_split(dims, params, prepared, nullptr, series, series_steps, label_start, rel_steps, h0, out, workspace,
+                          workspace_bytes, stream, &done));
+  if (done) return MATGCN_OK;
   MixPrecisionScope mixScope(true);
-  RETURN_IF(fuse_padded(c, series, x0p, label_start, rel_steps, series_steps));
-  RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
-  return head_padded(c, c.ws + P.oSeq[P.L - 1], out);
+  return forward_once(c, nullptr, series, series_steps, label_start, rel_steps, h0, out);
 }
 
 int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, const float* X, float* x0,

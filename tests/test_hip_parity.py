@@ -382,3 +382,38 @@ def test_backward_synth4096_vs_fp64_oracle(lib_built):
         elif max_norm_err(grads[k].cpu().numpy(), w) > 1e-4:
             bad[k] = max_norm_err(grads[k].cpu().numpy(), w)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["tiny_multi_uni_c2", "tiny_multi_uni_c2_static", "tiny_heads_331", "tiny_od_non_c3",
+                                  "tiny_multi_uni_dyn7", "dc237_out12", "bm403_out24"])
+def test_batch_split_forward_equals_two_half_batch_forwards(name, lib_built):
+    """matgcn_set_batch_split(2): the two halves of the batch as two independent forwards side by side (two streams,
+    two wavefront sets, two halves of the workspace).  Samples never interact, so the result must be BITWISE that of
+    forwards of B / 2 samples each, and within the end-to-end tolerance of the reference's prediction."""
+    from multistgraph_amd.ops import HotPath
+    c = Case(name)
+    if c.b % 2:
+        pytest.skip("odd batch: the split does not apply")
+    hp, dev = _path(c, lib_built)
+    x = torch.from_numpy(c.x).to(dev)
+    h0 = c.h0()
+    h0 = None if h0 is None else h0.to(dev)
+    plain = hp.forward(x, h0).clone()
+    prev = hp.lib.matgcn_set_batch_split(2)
+    try:
+        split = hp.forward(x, h0).clone()
+        again = hp.forward(x, h0).clone()
+    finally:
+        hp.lib.matgcn_set_batch_split(prev)
+    assert torch.equal(split, again)
+    assert max_norm_err(split.cpu().numpy(), c.gold["pred"]) <= E2E_TOL
+    assert elementwise_excess(split.cpu().numpy(), c.gold["pred"]) <= 1.0
+    # the same as forwards of the half batch (32-row work items for B / 2 <= 32; same arithmetic per sample)
+    hb = c.b // 2
+    half = HotPath(hp.spec, hb, dev)
+    half.bind({k: torch.from_numpy(v).to(dev) for k, v in c.state.items()}, hp._static)
+    for i in range(2):
+        hh = None if h0 is None else h0[:, i * hb:(i + 1) * hb].contiguous()
+        want = half.forward(x[i * hb:(i + 1) * hb].contiguous(), hh)
+        assert torch.equal(split[i * hb:(i + 1) * hb], want), i
+    assert max_norm_err(split.cpu().numpy(), plain.cpu().numpy()) <= 1e-5     # and equal to the unsplit forward to rounding
