@@ -340,6 +340,18 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
  * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting. */
 int matgcn_set_wavefront(int enabled);
 
+/* Lazy prepare.  By default `prepared` is complete, in stream order, when matgcn_prepare returns.  With
+ * matgcn_set_lazy_prepare(1) matgcn_prepare returns while the node-adaptive weight streams (most of its work) are still
+ * being written on two library streams, and every entry point of this library that takes `prepared` orders its stream
+ * behind them itself - the wavefront forward per layer: each chain waits for exactly the weights it reads, so the weight
+ * preparation runs beside head fusion, the layer-0 fold and the first graph mix of matgcn_forward{,_series}.  A caller
+ * that enables it promises (a) to keep `prepared` and the parameter tensors alive and unmodified until a later call of
+ * this library on the same stream has been enqueued, and (b) to call matgcn_prepare_join(stream) before it reads or
+ * frees `prepared` itself.  Meant for hosts that own `prepared` for the lifetime of the model (the plugin class does).
+ * Both return MATGCN_OK / the previous setting. */
+int matgcn_set_lazy_prepare(int enabled);
+int matgcn_prepare_join(void* stream);
+
 /* matgcn_set_batch_split(2): the inference forwards (matgcn_forward, matgcn_forward_series) run the two halves of an
  * even batch as two independent forwards of B / 2 samples side by side - half 0 on the caller's stream, half 1 on a
  * library stream, each with its own layer wavefront and its own half of the workspace - and join them before the call's

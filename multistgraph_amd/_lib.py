@@ -113,6 +113,8 @@ _SIGNATURES = {
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
     "matgcn_set_mix_precision": (C.c_int, [C.c_int]),
     "matgcn_set_batch_split": (C.c_int, [C.c_int]),
+    "matgcn_set_lazy_prepare": (C.c_int, [C.c_int]),
+    "matgcn_prepare_join": (C.c_int, [_P]),
     "matgcn_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "matgcn_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "matgcn_profile_disable": (C.c_int, []),
@@ -141,6 +143,10 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.matgcn_abi_version() != ABI_VERSION:
         raise MatgcnError("libmatgcn.so ABI version %d, binding expects %d" % (lib.matgcn_abi_version(), ABI_VERSION))
+    # this binding owns `prepared` for the lifetime of a HotPath and reads it only through the library (or behind
+    # matgcn_prepare_join): matgcn_prepare may leave its weight streams running beside the start of the next forward
+    if os.environ.get("MATGCN_LAZY_PREPARE", "1") != "0":
+        lib.matgcn_set_lazy_prepare(1)
     _lib = lib
     return lib
 

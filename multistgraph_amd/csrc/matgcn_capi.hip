@@ -337,6 +337,48 @@ struct SplitStreams {            // the second half's "caller stream" and the fo
 };
 SplitStreams g_split[MAX_DEVICES];
 int g_batch_split = 0;          // matgcn_set_batch_split: 0 / 1 off, 2 = two halves
+
+// Lazy prepare (matgcn_set_lazy_prepare(1); off by default: the plain contract is "prepared is complete in stream order
+// when matgcn_prepare returns").  The node-adaptive weight streams - 250 MB, most of matgcn_prepare's time - are written
+// on two library streams; with the option on, matgcn_prepare does NOT join them into the caller's stream but leaves four
+// events behind: the weights of layer 0 (needed by the first gate kernel, ~100 us into a forward) and of the layers
+// above (needed when their chains start, later still), each on both streams.  Every entry point that takes `prepared`
+// orders its stream behind all four first (make_ctx) - except the wavefront forward, which lets every chain wait for
+// exactly what it reads, so the weight preparation runs beside head fusion, the layer-0 fold and the first graph mix.
+struct PrepEvents {
+  bool ready = false, pending = false;
+  hipEvent_t l0[2], l1[2];
+};
+PrepEvents g_prep[MAX_DEVICES];
+int g_lazy_prepare = 0;
+inline PrepEvents& prep_current() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  return g_prep[dev];
+}
+int prep_events_ready() {
+  PrepEvents& E = prep_current();
+  if (E.ready) return MATGCN_OK;
+  for (int i = 0; i < 2; ++i) {
+    HIP_OK(hipEventCreateWithFlags(&E.l0[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&E.l1[i], hipEventDisableTiming));
+  }
+  E.ready = true;
+  return MATGCN_OK;
+}
+// stream s waits for what the last lazy matgcn_prepare may still be writing: which & 1 - the weight streams of layer 0,
+// which & 2 - those of the layers above.  (Waiting on an event that has completed costs nothing on the device.)
+int prep_wait(hipStream_t s, int which) {
+  PrepEvents& E = prep_current();
+  if (!E.pending) return MATGCN_OK;
+  for (int i = 0; i < 2; ++i) {
+    if (which & 1) HIP_OK(hipStreamWaitEvent(s, E.l0[i], 0));
+    if (which & 2) HIP_OK(hipStreamWaitEvent(s, E.l1[i], 0));
+  }
+  return MATGCN_OK;
+}
+
+
 #define g_wf (wf_current())
 int g_wavefront_mode = 1;     // matgcn_set_wavefront: 0 serial, 1 free-running chains
 int g_mix_precision = 0;      // matgcn_set_mix_precision: 0 fp32 operands, 1 bf16 operands for the inference graph mixes,
@@ -703,6 +745,9 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
   RETURN_IF(wavefront_ready());
   Wavefront& W = g_wf;
   const bool multi = P.L > 1 && g_wavefront_mode != 0;
+  const bool lazyPrep = prep_current().pending;
+  // one stream, the bf16 copies (they read every stream) and the dense-GRU ablation take everything up front
+  if (lazyPrep && (!multi || g_node_bf16_now || P.gcnOff)) RETURN_IF(prep_wait(c.s, 3));
   if (g_node_bf16_now && !P.gcnOff && !c.train) {
     // precision mode 2: bf16 copies of the recurrent weight streams into the workspace, once per forward and in front
     // of the fork (every chain reads them); 240 MB of traffic, part of what the side line's time includes
@@ -721,6 +766,10 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
     for (int l = 1; l < P.L; ++l) {
       HIP_OK(hipStreamWaitEvent(W.chain[l], W.fork, 0));
       HIP_OK(hipStreamWaitEvent(W.xpart[l], W.fork, 0));
+      if (lazyPrep) {   // the upper layers' chains and x-part streams read the upper layers' weight streams
+        RETURN_IF(prep_wait(W.chain[l], 2));
+        RETURN_IF(prep_wait(W.xpart[l], 2));
+      }
     }
   }
   if (!P.gcnOff) RETURN_IF(fold_x0(c, x0p, P.T, c.s));
@@ -801,6 +850,9 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
                       seq + t * stepRows, &res);
       RETURN_IF(cell_phase(c, l, t, 0, nullptr, &res, cs));
       if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.mixed[l][t], cs));
+      // layer 0's weight streams are first read here: head fusion, the fold of x0 and the first mix ran beside their
+      // preparation (lazy prepare)
+      if (lazyPrep && multi && l == 0 && t == 0) RETURN_IF(prep_wait(cs, 1));
       RETURN_IF(cell_phase(c, l, t, 1, nullptr, &res, cs));
       RETURN_IF(cell_phase(c, l, t, 2, nullptr, &res, cs));
       RETURN_IF(cell_phase(c, l, t, 3, nullptr, &res, cs));
@@ -850,13 +902,15 @@ int head_padded(const Ctx& c, const float* seqp, float* out) {
   return launch_ok();
 }
 
+// joinPrepare = false: the caller (the wavefront forward) orders its streams behind a lazy matgcn_prepare itself
 int make_ctx(Ctx* c, const matgcn_dims* dims, const matgcn_params* params, const void* prepared, void* workspace,
-             size_t workspace_bytes, void* stream) {
+             size_t workspace_bytes, void* stream, bool joinPrepare = true) {
   if (!dims || !params || !workspace) return MATGCN_ERR_NULL;
   RETURN_IF(make_plan(dims, &c->P));
   if (workspace_bytes < (size_t)c->P.workspaceFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   c->D = dims; c->prm = params; c->prep = (const float*)prepared; c->ws = (float*)workspace;
   c->s = (hipStream_t)stream;
+  if (prepared && joinPrepare) RETURN_IF(prep_wait(c->s, 3));
   return MATGCN_OK;
 }
 
@@ -964,6 +1018,16 @@ int matgcn_metric_table(const double* sums, int out_steps, int swap_r2, double* 
   if (out_steps < 1 || out_steps > 64) return MATGCN_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_metric_table, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out_steps, swap_r2, table);
   return launch_ok();
+}
+
+int matgcn_set_lazy_prepare(int enabled) {
+  const int prev = g_lazy_prepare;
+  g_lazy_prepare = enabled ? 1 : 0;
+  return prev;
+}
+
+int matgcn_prepare_join(void* stream) {
+  return prep_wait((hipStream_t)stream, 3);
 }
 
 int matgcn_set_batch_split(int parts) {
@@ -1123,6 +1187,10 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   Wavefront& W = g_wf;
   hipStream_t pool[3] = {c.s, W.chain[1], W.xpart[1]};
   const bool fork = g_wavefront_mode != 0;
+  const bool lazy = fork && g_lazy_prepare != 0;   // leave the weight streams running behind events (see PrepEvents)
+  PrepEvents& E = prep_current();
+  if (lazy) RETURN_IF(prep_events_ready());
+  E.pending = false;                               // what an earlier lazy prepare left behind was joined by make_ctx above
   if (fork) {
     HIP_OK(hipEventRecord(W.fork, c.s));
     HIP_OK(hipStreamWaitEvent(pool[1], W.fork, 0));
@@ -1137,7 +1205,9 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
       const matgcn_agcn_params& ap = part == 0 ? params->gate[l] : params->update[l];
       const int O = part == 0 ? 128 : 64;
       const int nG = 4 * P.Ktot;
-      hipStream_t ws = fork ? pool[(++piece) % 3] : c.s;
+      // lazy: the pieces alternate between the two library streams only (layer 0 first on both, so that its events come
+      // early; the gate piece is twice the update piece: the order flips per layer to balance the streams)
+      hipStream_t ws = !fork ? c.s : lazy ? pool[1 + ((part + l) & 1)] : pool[(++piece) % 3];
       PrepStream q;
       memset(&q, 0, sizeof(q));
       q.E = params->node_emb; q.wpool = ap.weights_pool; q.bpool = ap.bias_pool;
@@ -1167,6 +1237,10 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
         CHECK_LAUNCH();
       }
     }
+    if (lazy && l == 0) {   // layer 0's weight streams are complete on both library streams
+      HIP_OK(hipEventRecord(E.l0[0], pool[1]));
+      HIP_OK(hipEventRecord(E.l0[1], pool[2]));
+    }
     const int nG1 = (P.Cpad[l] + H) / 16;
     hipLaunchKernelGGL(k_prep_linear16, dim3(blocks_for((size_t)nG1 * 8 * 64)), dim3(256), 0, c.s,
                        params->res_gate[l].weight, I, 128, P.Cl[l], P.Cpad[l], nG1, prep + P.oRg[l]);
@@ -1178,7 +1252,11 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   hipLaunchKernelGGL(k_prep_linear, dim3(blocks_for((size_t)(P.headT * H / 8) * P.NTc * 64)), dim3(256), 0, c.s,
                      params->end_conv_weight, P.headT * H, P.CH, 0, 0, P.headT * H, P.NTc, prep + P.oHead);
   CHECK_LAUNCH();
-  if (fork) {
+  if (lazy) {          // no join: every consumer waits for what it reads (make_ctx, encoder_chains)
+    HIP_OK(hipEventRecord(E.l1[0], pool[1]));
+    HIP_OK(hipEventRecord(E.l1[1], pool[2]));
+    E.pending = true;
+  } else if (fork) {
     HIP_OK(hipEventRecord(W.done[1], pool[1]));
     HIP_OK(hipEventRecord(W.done[2], pool[2]));
     HIP_OK(hipStreamWaitEvent(c.s, W.done[1], 0));
@@ -1223,8 +1301,8 @@ static int forward_split(const matgcn_dims* dims, const matgcn_params* params, c
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
   SplitStreams& S = g_split[dev];
-  RETURN_IF(make_ctx(&c0, &half, params, prepared, workspace, halfBytes, stream));
-  RETURN_IF(make_ctx(&c1, &half, params, prepared, (char*)workspace + halfBytes, halfBytes, S.s1));
+  RETURN_IF(make_ctx(&c0, &half, params, prepared, workspace, halfBytes, stream, false));
+  RETURN_IF(make_ctx(&c1, &half, params, prepared, (char*)workspace + halfBytes, halfBytes, S.s1, false));
   const size_t layerStride = (size_t)dims->batch * dims->nodes * H;
   c0.h0LayerStride = c1.h0LayerStride = layerStride;
   const int hb = half.batch;
@@ -1252,7 +1330,7 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
                    const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared || !X || !out) return MATGCN_ERR_NULL;
   Ctx c;
-  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream, false));   // chains wait per layer
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));
@@ -1281,7 +1359,7 @@ int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, 
                           size_t workspace_bytes, void* stream) {
   if (!prepared || !series || !label_start || !rel_steps || !out) return MATGCN_ERR_NULL;
   Ctx c;
-  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream, false));   // chains wait per layer
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));

@@ -386,6 +386,19 @@ class HotPath:
         if not self._prepared_ok:
             self.prepare()
 
+    def prepare_join(self):
+        """the current stream waits for whatever a lazy matgcn_prepare still writes (include/matgcn.h): needed only by
+        code that reads ``self.prepared`` itself instead of through the library"""
+        _lib.check(self.lib.matgcn_prepare_join(self._stream()), "matgcn_prepare_join")
+
+    def __del__(self):
+        # `prepared` goes back to torch's allocator when this object dies: nothing of the library may still write it
+        try:
+            if self._prepared_ok and torch.cuda.is_available():
+                self.lib.matgcn_prepare_join(self._stream())
+        except Exception:
+            pass
+
     def _source(self, x):
         """The batch of a training step: a windows tensor X (B, x_steps, N, F), or a (series, label_start, rel_steps)
         triple - the raw series (T, N, F) resident on the device, B int32 label starts, the x_steps row offsets.
@@ -635,6 +648,7 @@ class HotPath:
         (tests).  Diagonal supports never reach the stack - they are folded into the identity slot of the node-adaptive
         weights (read those back with node_weights) -, and cheb_order = 1 holds the SUM of its dense supports."""
         self._need_prepared()
+        self.prepare_join()
         lay = (C.c_int64 * 4)()
         _lib.check(self.lib.matgcn_supports_layout(C.byref(self.dims), C.byref(lay)), "matgcn_supports_layout")
         off, ld, npad, ks = (int(v) for v in lay)
@@ -649,6 +663,7 @@ class HotPath:
         agru_cells[layer].gate (part 0, O = 128) / .update (part 1, O = 64), decoded from the MFMA-fragment-ordered
         stream matgcn_prepare wrote into `prepared` (tests: softmax(weights_g) and the diagonal-support fold included)."""
         self._need_prepared()
+        self.prepare_join()
         lay = (C.c_int64 * 4)()
         _lib.check(self.lib.matgcn_weights_layout(C.byref(self.dims), layer, part, C.byref(lay)),
                    "matgcn_weights_layout")
