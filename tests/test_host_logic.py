@@ -232,3 +232,38 @@ def test_same_seed_gives_the_reference_initial_weights(name, extra):
         for k in rs:
             assert rs[k].shape == os_[k].shape, k
             assert torch.equal(rs[k], os_[k]), "%s differs for seed %d" % (k, seed)
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path, lib_built):
+    """include/matgcn.h is the drop-in boundary: it must compile as plain C (C99, -pedantic) and a C program that only
+    includes it must link against libmatgcn.so and run the GPU-free entry points (status codes, sizes, argument checks)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include "matgcn.h"
+int main(void) {
+  matgcn_dims d;
+  size_t bytes = 0;
+  memset(&d, 0, sizeof(d));
+  if (matgcn_abi_version() != MATGCN_ABI_VERSION) return 1;
+  if (matgcn_prepared_bytes(&d, &bytes) == MATGCN_OK) return 2;            /* all-zero dims are refused */
+  if (matgcn_prepared_bytes(&d, NULL) != MATGCN_ERR_NULL) return 3;
+  if (!matgcn_error_string(MATGCN_ERR_BAD_ARG)) return 4;
+  if (matgcn_set_batch_split(0) != 0 || matgcn_set_mix_precision(0) != 0) return 5;
+  printf("abi %d ok\\n", matgcn_abi_version());
+  return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(lib_built)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                    "-L", libdir, "-lmatgcn", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env)
+    assert "abi 10 ok" in out.stdout
