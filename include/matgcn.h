@@ -17,6 +17,14 @@
  *   - matgcn_dims is a plain host struct, read at call time.
  *   - shapes use the reference's names: B batch, T = input_window (24), N nodes, H = rnn_units,
  *     F = feature dim of batch['X'], K = stacked supports including the identity.
+ *   - an entry point that fails between forking onto the library streams and joining them joins them into the caller's
+ *     stream before it returns its error code: the caller's buffers are quiet once its own stream is.
+ *
+ * ABI 10 (round 3) over ABI 9: matgcn_metric_sums / matgcn_metric_table (the evaluator's table and the group-std
+ * re-transform on the device), matgcn_series_violations (range contract of the series entry points: rows are clamped
+ * and counted, never read out of bounds), matgcn_set_mix_precision(2) (bf16 operands for the node-wise contractions),
+ * matgcn_set_batch_split, matgcn_set_lazy_prepare / matgcn_prepare_join; matgcn_workspace_bytes also covers two
+ * half-batch plans and the bf16 copies of the weight streams.  No signature of ABI 9 changed.
  */
 #ifndef MATGCN_H
 #define MATGCN_H

@@ -115,3 +115,63 @@ def test_fused_loss_gradient_matches_torch_autograd(lib_built):
     assert abs(float(loss) - float(want)) <= 2e-6 * abs(float(want))
     assert max_norm_err(p1.grad.cpu().numpy(), p2.grad.numpy()) <= 1e-6
     assert float(p1.grad[0, :, :4].abs().max()) == 0.0 and float(p1.grad[1, 2, 7, 0]) == 0.0
+
+
+def test_lazy_prepare_is_bitwise_the_eager_prepare(lib_built):
+    """matgcn_set_lazy_prepare(1) (on in this binding): matgcn_prepare leaves its weight streams running behind events
+    and every consumer waits for what it reads.  The same sequence of calls - parameter updates between forwards, two
+    batch sizes (two `prepared` buffers) interleaved, a training step in between, the read-back helpers, serial and
+    wavefront schedules - must give bitwise the results of the eager prepare (the C default)."""
+    from multistgraph_amd import _lib
+    from multistgraph_amd.model import MultiATGCN
+    c = Case("tiny_multi_uni_c2")
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+
+    def run(lazy):
+        prev = lib.matgcn_set_lazy_prepare(1 if lazy else 0)
+        try:
+            torch.manual_seed(3)
+            m = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+            m.cache_prepared = False                       # prepare in front of EVERY forward, as the bench does
+            x2 = torch.from_numpy(c.x).to(dev)
+            x6 = torch.cat([x2, x2.flip(0), x2 * 0.5], 0).contiguous()
+            y2 = torch.from_numpy(c.y).to(dev)
+            outs = []
+            m.eval()
+            with torch.no_grad():
+                outs.append(m.predict({"X": x2}).clone())
+                outs.append(m.predict({"X": x6}).clone())                  # a second HotPath / prepared buffer
+                m.node_emb.mul_(1.25)                                       # parameter update right after a forward
+                outs.append(m.predict({"X": x2}).clone())
+                hp = m._paths[2]
+                outs.append(hp.supports().clone())                          # read-back helpers join first
+                outs.append(hp.node_weights(1, 0).clone())
+                lib.matgcn_set_wavefront(0)
+                outs.append(m.predict({"X": x6}).clone())
+                lib.matgcn_set_wavefront(1)
+            m.train()
+            torch.manual_seed(5)
+            loss = m.calculate_loss({"X": x2, "y": y2})
+            loss.backward()
+            outs.append(loss.detach().clone())
+            outs.append(m.node_emb.grad.clone())
+            with torch.no_grad():
+                m.encoder.weights_gru.add_(0.1)
+            m.eval()
+            with torch.no_grad():
+                outs.append(m.predict({"X": x2}).clone())
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            lib.matgcn_set_wavefront(1)
+            lib.matgcn_set_lazy_prepare(prev)
+
+    eager, lazy = run(False), run(True)
+    assert len(eager) == len(lazy)
+    for i, (a, b) in enumerate(zip(eager, lazy)):
+        if i == 7:      # the node-embedding gradient accumulates with atomics (split-K): equal to rounding, not bitwise
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), i
+        else:
+            assert torch.equal(a, b), i
