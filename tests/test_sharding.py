@@ -181,3 +181,49 @@ def test_allreduce_model_grads_two_rank_gloo(tmp_path):
     world = 2
     mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("dp_ok%d" % r)).exists() for r in range(world))
+
+
+def _gpu_dp_worker(rank, world, port, out_dir):
+    """one data-parallel training step per rank on the ONE GPU of the box (gloo carries the collectives): different batch
+    shards, the real HIP backward, sharding.allreduce_model_grads_, Adam - the replicas must stay bit-identical"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import Case
+    from multistgraph_amd.model import MultiATGCN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        for name, has_bucket, has_rest in (("tiny_multi_uni_c2_static", True, True), ("hid32_multi_uni_c2", False, True),
+                                           ("tiny_multi_uni_c2", True, False)):
+            c = Case(name)
+            torch.manual_seed(11)
+            model = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            rng = np.random.default_rng(100 + rank)                       # every rank its own shard
+            x = torch.from_numpy(c.x + 0.1 * rng.standard_normal(c.x.shape).astype(np.float32)).to(dev)
+            y = torch.from_numpy(c.y).to(dev)
+            torch.manual_seed(50 + rank)                                  # and its own dropout mask
+            for _ in range(2):
+                opt.zero_grad()
+                loss = model.calculate_loss({"X": x, "y": y})
+                loss.backward()
+                info = sh.allreduce_model_grads_(model)
+                assert info["bucket"] == has_bucket and (info["leftover_elems"] > 0) == has_rest, (name, info)
+                opt.step()
+                assert sh.replicas_in_sync(model.parameters()), name
+        open(os.path.join(out_dir, "gpu_dp_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_training_steps_on_one_gpu(tmp_path):
+    """the data-parallel step end to end with two ranks sharing the box's GPU over gloo: a static-feature model (bucket +
+    the host-side layers' gradients), an rnn_units = 32 model (no bucket) and the plain model (bucket only)"""
+    world = 2
+    mp.spawn(_gpu_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("gpu_dp_ok%d" % r)).exists() for r in range(world))
