@@ -267,3 +267,20 @@ int main(void) {
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env)
     assert "abi 10 ok" in out.stdout
+
+
+def test_bench_flop_models_are_consistent():
+    """the executed-FLOP models of bench.py (what `whole_forward.frac_mfma` and `backward_frac_mfma` divide by): the
+    executed forward is below the SURVEY formula (dense supports only, x columns mixed once), and the backward lies
+    between 1.3 x and 2 x the executed forward (two GEMMs per forward GEMM, minus the adjacency gradients the static
+    supports do not have and the shared x-part mixes)"""
+    import bench
+    for n, b, out in ((403, 64, 24), (237, 64, 12), (4096, 32, 24)):
+        units = b * 24 * n
+        survey = bench.algorithmic_flops_per_unit(n, out=out) * units
+        fwd = bench.executed_flops_per_unit(n, 3, out=out) * units
+        bwd = bench.backward_executed_flops(n, b, 3, 5, out=out)
+        assert 0.5 * survey < fwd < survey
+        assert 1.3 * fwd < bwd < 2.0 * fwd, (n, bwd / fwd)
+    m = bench.step_kernel_models(403, 416, 64, 3)
+    assert abs(m["k_mix"]["flops"] - 2 * 3 * 403 * 403 * 64 * 64) < 1
