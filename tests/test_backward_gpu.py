@@ -466,6 +466,10 @@ def test_full_size_directional_derivative(lib_built):
     (21, 2, 3, {"adjtype": "cosine", "adpadj": "unidirection", "cheb_order": 3}),
     (21, 3, 2, {"end_dim": 2}),     # two flow channels: output_dim = 2 (MultiATGCN.py:320)
     (21, 2, 2, {"ext": 8}),         # add_day_in_week: time of day + 7 day-of-week channels (:313-318)
+    # the widest input of the reference's channel sweep (run_model_parameter.py:11-12, [True, True, True, ..]): time of
+    # day + 7 day-of-week channels + 5 dynamic variables = 14 input channels
+    (21, 2, 2, {"ext": 13}),
+    (16, 3, 1, {"ext": 0}),         # add_time_in_day off: the flow channel alone
 ])
 def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags, lib_built):
     """N a multiple of 16 (no padding rows anywhere), a batch that is not a multiple of the 64-row tile, and 1 / 3 / 4
@@ -479,7 +483,8 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     adjtype, adpadj = flags.get("adjtype", "multi"), flags.get("adpadj", "unidirection")
     od, ext = flags.get("end_dim", 1), flags.get("ext", 1)
     abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext")}
-    cfg = dict(input_window=24, output_window=6, add_time_in_day=True, add_day_in_week=ext == 8, load_dynamic=False,
+    cfg = dict(input_window=24, output_window=6, add_time_in_day=ext > 0, add_day_in_week=ext in (8, 13),
+               load_dynamic=ext == 13,
                adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
                num_layers=layers, device=torch.device("cpu"), batch_size=b, start_dim=0, end_dim=od, **abl)
     df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=ext), output_dim=od, feature_dim=od + ext)
@@ -501,8 +506,8 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     d_out = rng.standard_normal((b, 6, n, od)).astype(np.float32)
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state_np.items()}
     ocfg = dict(adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, num_layers=layers, rnn_units=64, len_closeness=48,
-                len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=True,
-                add_day_in_week=ext == 8, load_dynamic=False, start_dim=0, end_dim=od, **abl)
+                len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=ext > 0,
+                add_day_in_week=ext in (8, 13), load_dynamic=ext == 13, start_dim=0, end_dim=od, **abl)
     y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [m.double() for m in st] if use_static else [], ocfg,
                     faithful=False)
     (y * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
