@@ -22,7 +22,10 @@ namespace {
 
 constexpr int H = 64;
 constexpr int MAX_STEPS = 64;     // in_steps the wavefront scheduler keeps events for
-constexpr int X_CHUNK = 4;        // steps per hoisted x-part chunk of layers >= 1
+#ifndef X_CHUNK_STEPS
+#define X_CHUNK_STEPS 2
+#endif
+constexpr int X_CHUNK = X_CHUNK_STEPS;   // steps per hoisted x-part chunk of layers >= 1 (round 3: 1 / 2 / 3 equal, 4 +1 %, 8 +3 %)
 
 inline long rup(long v, long m) { return (v + m - 1) / m * m; }
 
