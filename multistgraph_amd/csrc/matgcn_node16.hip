@@ -332,8 +332,11 @@ inline unsigned node_items(int N, int rows, int blockRows) {
 
 // ---- gate AGCN + sigmoid + z*h (MultiATGCN.py:122-125) -----------------------------------------------------
 // wave w = column tile w of 8 (0..3: z, 4..7: r), all ROWS/16 row tiles.  LDS 3 chunks of ROWS x 64 floats: Hs | Gb[2]
+#ifndef NODE_MIN_WAVES_GATE
+#define NODE_MIN_WAVES_GATE NODE_MIN_WAVES
+#endif
 template <bool SAVE, int ROWS, bool BF = false>
-__global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_32) void k_gate16(Node16Args a) {
+__global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES_GATE : NODE_MIN_WAVES_32) void k_gate16(Node16Args a) {
   typedef typename NodeOp<BF>::T Op;
   constexpr int NRT = ROWS / 16, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
