@@ -1202,6 +1202,21 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
   int piece = 0;
   const StackMap map = build_stack_map(P, dims, params);
   const unsigned nodeGroups = (unsigned)((P.N + PREP_NB - 1) / PREP_NB);
+#ifndef PREP_KERNEL
+#define PREP_KERNEL 2      // 0: k_prep_stream (round 1, lab builds), 2: k_prep_mfma
+#endif
+#ifndef PREP_TPW
+#define PREP_TPW 4         // k_prep_mfma: 16-node tiles per wave (a workgroup = 4 waves walks 4 * PREP_TPW tiles)
+#endif
+  const bool fast = PREP_KERNEL == 2 && P.d <= 32;
+  const int nTiles = (P.N + 15) / 16, tilesPerBlock = 4 * PREP_TPW;
+  const unsigned tileBlocks = (unsigned)((nTiles + tilesPerBlock - 1) / tilesPerBlock);
+  auto launch_fast = [&](const PrepStream& q, int O, hipStream_t ws) {
+    const dim3 grid((unsigned)((q.groups + q.groupsX) * (O / 16) * 2), tileBlocks);
+    if (P.d <= 12) hipLaunchKernelGGL(k_prep_mfma<3>, grid, dim3(256), 0, ws, q, tilesPerBlock);
+    else if (P.d <= 20) hipLaunchKernelGGL(k_prep_mfma<5>, grid, dim3(256), 0, ws, q, tilesPerBlock);
+    else hipLaunchKernelGGL(k_prep_mfma<8>, grid, dim3(256), 0, ws, q, tilesPerBlock);
+  };
   for (int l = 0; l < P.L; ++l) {
     const int I = P.Cl[l] + H;
     for (int part = 0; part < 2 && !P.gcnOff; ++part) {  // 0 gate (O=128), 1 update (O=64)
@@ -1220,20 +1235,31 @@ int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* p
       q.out = prep + (part == 0 ? P.oWg[l] : P.oWu[l]);
       q.nodeStride = (long)(nG + P.nGx[l]) * 16 * O;
       q.baseOfs = 0; q.kind = 0; q.iOfs = P.Cl[l]; q.groups = nG;
-      hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
-                         ws, q);
+      if (fast) {     // layer 0: the folded x rows + bias row sit behind the recurrent rows - one launch writes both
+        q.groupsX = l == 0 ? P.nGx[0] : 0;
+        launch_fast(q, O, ws);
+        q.groupsX = 0;
+      } else {
+        hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
+                           ws, q);
+      }
       CHECK_LAUNCH();
       if (l == 0) {  // folded x rows + bias row, appended to the node stream
-        q.baseOfs = (long)nG * 16 * O; q.kind = 1; q.iOfs = 0; q.groups = P.nGx[0];
-        hipLaunchKernelGGL(k_prep_stream<1>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
-                           ws, q);
-        CHECK_LAUNCH();
+        if (!fast) {
+          q.baseOfs = (long)nG * 16 * O; q.kind = 1; q.iOfs = 0; q.groups = P.nGx[0];
+          hipLaunchKernelGGL(k_prep_stream<1>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
+                             ws, q);
+          CHECK_LAUNCH();
+        }
       } else {
         // hoisted x part: gate column tiles 0..7, update tiles 8..11 of a 192-wide fragment row (k_px16)
         q.out = prep + P.oWx[l]; q.nodeStride = P.wxStride; q.baseOfs = 0;
         q.kind = 0; q.iOfs = 0; q.groups = nG; q.OTdst = 12; q.otOfs = part == 0 ? 0 : 8;
-        hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
-                           ws, q);
+        if (fast)
+          launch_fast(q, O, ws);
+        else
+          hipLaunchKernelGGL(k_prep_stream<0>, dim3(blocks_for((size_t)q.groups * (O / 16) * 64), nodeGroups), dim3(256), 0,
+                             ws, q);
         CHECK_LAUNCH();
         hipLaunchKernelGGL(k_prep_bias, dim3(blocks_for((size_t)P.N * O)), dim3(256), 0, ws, params->node_emb,
                            ap.bias_pool, P.d, O, P.N, prep + P.oBx[l], 192, part == 0 ? 0 : 128);

@@ -50,6 +50,7 @@ struct PrepStream {
                          // 1: layer-0 folded x rows, 16x16x4 order   rows kk -> slot kk/C0, channel kk%C0, then bias row
   int iOfs, C0;
   int groups;            // k-groups of 16 rows
+  int groupsX;           // k_prep_mfma: kind-1 k-groups appended behind the `groups` kind-0 ones (same launch)
   int OTdst, otOfs;      // OTdst > 0: tiles per fragment row in the destination and first tile of this piece
                          // (the 192-column x-part stream takes the gate in tiles 0..7 and the update in 8..11)
   StackMap map;

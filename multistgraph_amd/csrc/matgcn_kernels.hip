@@ -261,6 +261,146 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepStream a) {
   }
 }
 
+// Round 3: the same streams on the matrix cores.  W[n][row][o] = sum_d pool[d][row][o] * E[n][d] is a GEMM with the embedding
+// dimension as its (short) reduction: A = 16 pool elements x d, B = d x 16 nodes, and the 16 A rows are chosen so that
+// the accumulator of a lane - rows 4 (l >> 4) + e, column l & 15 of the 16x16x4 fp32 MFMA - is exactly one float4 of the
+// fragment stream of node l & 15: rows 4 q + s of a "quad" are the four weight rows s of the float4 in slot j = 4 j4 + q
+// of lane group kq.  A wave keeps the A fragments of 8 quads (half a fragment row: 2 lane groups x 4 j4) in registers and
+// walks 16-node tiles; per tile it reads 4 ceil(d / 4) embedding values, issues 8 ceil(d / 4) MFMAs and stores 8 float4
+// per lane (64-byte pieces that the L2 merges into the node's 1 KB rows).  The exact-fp32 MFMA accumulates k = 0..3 in
+// order, so the sums are the fma chains of the kernel above.  DS = ceil(d / 4) steps are compiled in (3 / 5 / 8:
+// embeddings of up to 12 / 20 / 32; wider ones take the first kernel).  `groups` k-groups of kind-0 rows are followed by
+// `groupsX` k-groups of kind-1 rows (layer 0: the folded x rows and the bias row sit behind the recurrent rows of the same
+// node stream, so one launch writes both).  Measured at N = 403, d = 20 (profiles/r03_prep_lab.log): 27 us per launch
+// against 49 us (+ 35 us for the kind-1 launch) of the first kernel, which re-reads every pool value per 8 nodes and
+// spends 2 d VALU fmas per output; a VALU variant with the pool values in registers and a node loop was slower (68 us).
+template <int DS>
+__global__ __launch_bounds__(256) void k_prep_mfma(PrepStream a, int tilesPerBlock) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int OT = a.O >> 4;
+  const int pair = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int ct = pair % OT, g = pair / OT;
+  const int r = lane & 15, ka = lane >> 4;      // A operand: row r of the quad (slot r >> 2, weight row s = r & 3), d index ka
+  float gmax = -3.0e38f, gsum = 1.f;
+  if (a.wg) {
+    gsum = 0.f;
+    for (int k = 0; k < a.map.KtotOrig; ++k) gmax = fmaxf(gmax, a.wg[k]);
+    for (int k = 0; k < a.map.KtotOrig; ++k) gsum += expf(a.wg[k] - gmax);
+  }
+  auto gk = [&](int k) { return a.wg ? expf(a.wg[k] - gmax) / gsum : 1.f; };
+  const size_t dstride = (size_t)a.map.KtotOrig * a.I * a.O;
+  float A[8][DS], Aq[8][DS];
+  bool ident = false;
+#pragma unroll
+  for (int q8 = 0; q8 < 8; ++q8) {
+    const int kq = 2 * half + (q8 >> 2), j = 4 * (q8 & 3) + (r >> 2), sr = r & 3;
+    const int o = 16 * ct + j;
+    int slot, chan;
+    if (g < a.groups) {
+      const int kk = 16 * g + 4 * kq + sr;
+      slot = kk >> 6; chan = a.iOfs + (kk & 63);
+    } else {
+      const int kk = 16 * (g - a.groups) + 4 * kq + sr;
+      const int nx = a.map.nKeep * a.C0;
+      if (kk < nx) { slot = kk / a.C0; chan = kk - slot * a.C0; }
+      else { slot = kk == nx ? -2 : -1; chan = 0; }
+    }
+    const float* src = a.wpool; size_t sstep = 0; float scale = 0.f;
+    if (slot >= 0) {
+      const int k = a.map.keepK[slot];
+      src = a.wpool + ((size_t)k * a.I + chan) * a.O + o; sstep = dstride; scale = gk(k);
+    } else if (slot == -2) {
+      src = a.bpool + o; sstep = (size_t)a.O; scale = 1.f;
+    }
+    const bool id = slot == 0 && a.map.nDiag > 0;
+    ident = ident || id;
+    const float* srcq = id ? a.wpool + ((size_t)a.map.diagK[0] * a.I + chan) * a.O + o : a.wpool;
+#pragma unroll
+    for (int st = 0; st < DS; ++st) {
+      const int dd = 4 * st + ka;
+      const float v = src[(size_t)min(dd, a.d - 1) * sstep];
+      A[q8][st] = (dd < a.d && slot != -1) ? v * scale : 0.f;
+      const float vq = srcq[(size_t)min(dd, a.d - 1) * (id ? dstride : 0)];
+      Aq[q8][st] = (dd < a.d && id) ? vq : 0.f;
+    }
+  }
+  const bool anyIdent = __ballot(ident) != 0ull;
+  const int nTiles = (a.N + 15) >> 4;
+  const int tile0 = blockIdx.y * tilesPerBlock, tile1 = min(tile0 + tilesPerBlock, nTiles);
+  const int nodeL = lane & 15, kb = lane >> 4;   // B operand / accumulator: node of the tile, d index; slot quarter kb
+  auto load_b = [&](int tile, float (&Bf)[DS]) {
+    const float* e = a.E + (size_t)min(tile * 16 + nodeL, a.N - 1) * a.d;
+#pragma unroll
+    for (int st = 0; st < DS; ++st) {
+      const int dd = 4 * st + kb;
+      const float v = e[min(dd, a.d - 1)];
+      Bf[st] = dd < a.d ? v : 0.f;
+    }
+  };
+  float Bf[DS], Bn[DS];
+  if (tile0 + w < tile1) load_b(tile0 + w, Bf);
+  for (int tile = tile0 + w; tile < tile1; tile += 4) {
+    load_b(min(tile + 4, tile1 - 1), Bn);
+    const int n = tile * 16 + nodeL;
+    f32x4 acc[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) acc[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < DS; ++st)
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) acc[q8] = MFMA16(A[q8][st], Bf[st], acc[q8]);
+    if (anyIdent) {
+      const int nc = min(n, a.N - 1);
+      for (int q = 0; q < a.map.nDiag; ++q) {
+        f32x4 part[8];
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) part[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) {
+#pragma unroll
+          for (int st = 0; st < DS; ++st)
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) part[q8] = MFMA16(Aq[q8][st], Bf[st], part[q8]);
+        } else {   // further diagonal supports: their pool values are re-read (rare)
+          const int k = a.map.diagK[q];
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) {
+            const int kq = 2 * half + (q8 >> 2), j = 4 * (q8 & 3) + (r >> 2), sr = r & 3;
+            int slot, chan;
+            if (g < a.groups) { const int kk = 16 * g + 4 * kq + sr; slot = kk >> 6; chan = a.iOfs + (kk & 63); }
+            else {
+              const int kk = 16 * (g - a.groups) + 4 * kq + sr;
+              if (kk < a.map.nKeep * a.C0) { slot = kk / a.C0; chan = kk - slot * a.C0; } else { slot = -1; chan = 0; }
+            }
+#pragma unroll
+            for (int st = 0; st < DS; ++st) {
+              const int dd = 4 * st + ka;
+              const float v = a.wpool[(size_t)min(dd, a.d - 1) * dstride + ((size_t)k * a.I + chan) * a.O + 16 * ct + j];
+              part[q8] = MFMA16((dd < a.d && slot == 0) ? v : 0.f, Bf[st], part[q8]);
+            }
+          }
+        }
+        const float t = gk(a.map.diagK[q]) *
+                        cheb_scalar(a.map.diagSrc[q][(size_t)nc * (a.map.N + 1)], a.map.diagOrder[q]);
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[q8][e] = fmaf(t, part[q8][e], acc[q8][e]);
+      }
+    }
+    if (n < a.N) {
+      float* dst = a.out + (size_t)n * a.nodeStride + a.baseOfs;
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) {
+        const int kq = 2 * half + (q8 >> 2), j = 4 * (q8 & 3) + kb;
+        const size_t frag = ((size_t)(a.OTdst > 0 ? g * a.OTdst + a.otOfs + ct : g * OT + ct) * 64 + kq * 16 + j) * 4;
+        *reinterpret_cast<float4*>(dst + frag) = make_float4(acc[q8][0], acc[q8][1], acc[q8][2], acc[q8][3]);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < DS; ++st) Bf[st] = Bn[st];
+  }
+}
+
 // bias[n][colOfs + o] = E[n] . bpool[:, o]   (hoisted-PX layers)
 __global__ __launch_bounds__(256) void k_prep_bias(const float* __restrict__ E, const float* __restrict__ bpool, int d,
                                                    int O, int N, float* __restrict__ out, int ldo, int colOfs) {
