@@ -674,7 +674,19 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
     }
     const long cols = (long)rowsTB * C;
     float* MixN = tr + R.oMixN;
-    if (P.Ks > 0) {
+    if (P.Ks > 0 && cols % 64 == 0 && (long)N * cols < (1L << 29)) {
+      // the graph-mix kernel on the plain stack, 64 of the rows*C columns per tile (as the forward folds x0): the generic
+      // GEMM ran this 3 GFLOP product at 13 TFLOP/s - in the tail of the backward, where nothing hides it
+      MixArgs a;
+      a.St = tr + R.oStP; a.ldS = P.NpC;
+      a.X = DAx + (size_t)Np * cols; a.xTileStride = 64; a.ldX = (int)cols;
+      a.out = MixN; a.sN = cols; a.sK = 0; a.sT = 64;
+      a.outFloats = (long)N * cols;
+      a.Np = P.NpC; a.N = N; a.Ks = 1; a.nK = P.Ks * Np / 16; a.nColTiles = (int)(cols / 64);
+      a.nRowTiles = P.NpC / 64;
+      hipLaunchKernelGGL(k_mix<2>, dim3((unsigned)(a.nRowTiles * a.nColTiles), 1u), dim3(256), 0, s, a);
+      CHECK_LAUNCH();
+    } else if (P.Ks > 0) {
       GemmArgs q = gemm_args(c.prep + P.oSt, DAx + (size_t)Np * cols, MixN, N, (int)cols, P.Ks * Np);
       q.sAm = P.Mp; q.sAk = 1; q.sBk = cols; q.sBn = 1; q.sCm = cols; q.sCn = 1;
       RETURN_IF(gemm(q, 1, s, BG_X_MIX));
@@ -690,7 +702,13 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
                        (size_t)rowsTB, Np, C, S);
     CHECK_LAUNCH();
   }
-  {  // residual cell x columns
+  const long rrows = (long)rowsTB * Np;
+  if (narrow && (C == 2 || C == 9)) {   // residual cell x columns of a narrow input: one pass over the 192 gradients per row
+    const dim3 grid((unsigned)((rrows + 15) / 16 < 4096 ? (rrows + 15) / 16 : 4096));
+    if (C == 2) hipLaunchKernelGGL(k_res_xcol_narrow<2>, grid, dim3(256), 0, s, DPU2, DPG2, RU, RG, I, dXall, rrows);
+    else hipLaunchKernelGGL(k_res_xcol_narrow<9>, grid, dim3(256), 0, s, DPU2, DPG2, RU, RG, I, dXall, rrows);
+    CHECK_LAUNCH();
+  } else {  // residual cell x columns
     GemmArgs q = gemm_args(DPU2, RU, dXall, rowsTB * Np, C, H);
     q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
     RETURN_IF(gemm(q, 1, s));
@@ -728,9 +746,16 @@ int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const f
   RETURN_IF(zero_async(gg.bias, 128, xs));
   RETURN_IF(zero_async(gu.bias, 64, xs));
   bool biasG = false, biasU = false;   // the h-column GEMMs (64 input channels: fast kernel) take the bias sums along
-  RETURN_IF(linear_weight_grad(bx, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+  if (narrow && (C == 2 || C == 9)) {   // both x-column blocks in one pass over the residual cell's gradients
+    const dim3 grid((unsigned)((rows + 15) / 16 < 1024 ? (rows + 15) / 16 : 1024));
+    if (C == 2) hipLaunchKernelGGL(k_res_wgrad_narrow<2>, grid, dim3(256), 0, xs, DPU2, DPG2, Xall, I, gu.weight, gg.weight, rows);
+    else hipLaunchKernelGGL(k_res_wgrad_narrow<9>, grid, dim3(256), 0, xs, DPU2, DPG2, Xall, I, gu.weight, gg.weight, rows);
+    CHECK_LAUNCH();
+  } else {
+    RETURN_IF(linear_weight_grad(bx, DPG2, 128, Xall, C, rows, I, 0, gg.weight));
+    RETURN_IF(linear_weight_grad(bx, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
+  }
   RETURN_IF(linear_weight_grad(bx, DPG2, 128, HA, H, rows, I, C, gg.weight, gg.bias, &biasG));
-  RETURN_IF(linear_weight_grad(bx, DPU2, 64, Xall, C, rows, I, 0, gu.weight));
   RETURN_IF(linear_weight_grad(bx, DPU2, 64, Z2HA, H, rows, I, C, gu.weight, gu.bias, &biasU));
   if (!biasG) {   // (the rows of the padding nodes are zero in DPG2 / DPU2: summing them with the operand stream is exact)
     hipLaunchKernelGGL(k_colsum_all, dim3(1024), dim3(256), 0, xs, DPG2, (size_t)rowsTB, N, Np, 128, 128, gg.bias);
@@ -845,13 +870,17 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
 #define WN_LAUNCH(C0_, S_)                                                                                               \
   hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N, WN_PARTS), dim3(192 * WN_GROUPS), 0, ws, Xall,          \
                      c.ws + P.oMX0, ld, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
-    if (P.C0 == 2 && S == 4) WN_LAUNCH(2, 4);
-    else if (P.C0 == 2 && S == 5) WN_LAUNCH(2, 5);
-    else if (P.C0 == 2 && S == 2) WN_LAUNCH(2, 2);
-    else if (P.C0 == 2 && S == 1) WN_LAUNCH(2, 1);
+#define WNM_LAUNCH(C0_, S_)                                                                                              \
+  hipLaunchKernelGGL((k_wgrad_narrow_mfma<C0_, S_>), dim3((unsigned)N, WNM_PARTS), dim3(256), 0, ws, Xall, c.ws + P.oMX0,  \
+                     ld, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
+    if (P.C0 == 2 && S == 4) WNM_LAUNCH(2, 4);
+    else if (P.C0 == 2 && S == 5) WNM_LAUNCH(2, 5);
+    else if (P.C0 == 2 && S == 2) WNM_LAUNCH(2, 2);
+    else if (P.C0 == 2 && S == 1) WNM_LAUNCH(2, 1);
     else if (P.C0 == 9 && S == 4) WN_LAUNCH(9, 4);
     else narrowDone = false;
 #undef WN_LAUNCH
+#undef WNM_LAUNCH
     if (narrowDone) {
       CHECK_LAUNCH();
     } else {
@@ -950,7 +979,16 @@ int bwd_pools_layer(Pass& pass, int l, hipStream_t onStream) {
       bool distinct = ent.n <= 8;
       for (int e2 = 0; e2 < ent.n && distinct; ++e2)
         for (int e3 = 0; e3 < e2; ++e3) distinct = distinct && ent.pool[e3] != ent.pool[e2];
-      if (distinct && ent.n > 0) {
+      if (distinct && ent.n > 0 && P.d <= 32 && IO % 64 == 0) {
+        // both products on the matrix cores with d as two 16-wide tiles (k_pool_grad_mfma / k_pool_emb_mfma)
+        hipLaunchKernelGGL(k_pool_grad_mfma, dim3((unsigned)((IO / 64 + 3) / 4), (unsigned)ent.n), dim3(256), 0, s, EK, dWp,
+                           ent, N, P.d, IO, S, Kt, ag.weights_pool);
+        CHECK_LAUNCH();
+        const int splits = 4;
+        hipLaunchKernelGGL(k_pool_emb_mfma, dim3((unsigned)(((N + 15) / 16) * splits), (unsigned)ent.n), dim3(256), 0, s,
+                           dWp, ap.weights_pool, ent, N, P.d, IO, S, Kt, splits, TmpK);
+        CHECK_LAUNCH();
+      } else if (distinct && ent.n > 0) {
         GemmArgs q = gemm_args(EK, dWp, ag.weights_pool, P.d, (int)IO, N);
         q.sAm = 1; q.sAk = P.d; q.sBk = (long)S * IO; q.sBn = 1; q.sCm = (long)Kt * IO; q.sCn = 1;
         GemmArgs e = gemm_args(dWp, ap.weights_pool, TmpK, N, P.d, (int)IO);

@@ -407,6 +407,112 @@ __global__ __launch_bounds__(256) void k_scaled_emb(const float* __restrict__ E,
   if (idx % d == 0) FK[(size_t)e * map.N + n] = f;
 }
 
+// ---- the two pool-gradient products on the matrix cores (round 3) ---------------------------------------------------
+// Both have the embedding dimension d (<= 32) as one side of the product: on 64 x 64 GEMM tiles (k_bgemm<BG_POOL>) two
+// thirds of every tile were padding and the plain weight gradients dWp (250 MB per backward) streamed through the scalar
+// path of the generic kernel.  The 16x16x4 fp32 MFMA takes d as 2 tiles of 16 and reads dWp as whole float4s:
+//
+// (1) dWpool[dd][pool(e)][io] = sum_n EK[e][n][dd] * dWp[n][slot(e)][io]           (transpose of k_prep_mfma)
+//     A = EK^T (rows dd, reduction n), B = dWp (reduction n, columns io).  A lane's float4 of a node's row holds the
+//     SAME column of four column tiles (column 4 (l & 15) + ct of the wave's 64), so one 256-byte row piece per node
+//     feeds eight MFMAs, and the accumulators leave as float4 stores of four consecutive columns.
+//     One wave per (entry, 64 columns); entries with distinct pool indices only (cheb_order = 1 keeps the GEMMs).
+__global__ __launch_bounds__(256) void k_pool_grad_mfma(const float* __restrict__ EK, const float* __restrict__ dWp,
+                                                        StackEntries ent, int N, int d, long IO, int S, int Kt,
+                                                        float* __restrict__ dPool) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, j = lane & 15;
+  const int e = blockIdx.y;
+  const long col0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (col0 >= IO) return;
+  const float* ek = EK + (size_t)e * N * d;
+  const float* src = dWp + (size_t)ent.slot[e] * IO + col0 + 4 * j;
+  const size_t nodeStride = (size_t)S * IO;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[r][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (N + 3) >> 2;
+  auto load = [&](int st, float4& b, float& a0, float& a1) {
+    const int node = 4 * st + kq, nc = min(node, N - 1);
+    b = *reinterpret_cast<const float4*>(src + (size_t)nc * nodeStride);
+    const float v0 = ek[(size_t)nc * d + min(j, d - 1)], v1 = ek[(size_t)nc * d + min(16 + j, d - 1)];
+    a0 = (node < N && j < d) ? v0 : 0.f;
+    a1 = (node < N && 16 + j < d) ? v1 : 0.f;
+  };
+  float4 b[4];
+  float a0[4], a1[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) load(min(u, steps - 1), b[u], a0[u], a1[u]);
+  for (int st = 0; st < steps; st += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 bv = b[u];
+      const float x0 = st + u < steps ? a0[u] : 0.f, x1 = st + u < steps ? a1[u] : 0.f;
+      load(min(st + u + 4, steps - 1), b[u], a0[u], a1[u]);
+      acc[0][0] = MFMA16(x0, bv.x, acc[0][0]); acc[1][0] = MFMA16(x1, bv.x, acc[1][0]);
+      acc[0][1] = MFMA16(x0, bv.y, acc[0][1]); acc[1][1] = MFMA16(x1, bv.y, acc[1][1]);
+      acc[0][2] = MFMA16(x0, bv.z, acc[0][2]); acc[1][2] = MFMA16(x1, bv.z, acc[1][2]);
+      acc[0][3] = MFMA16(x0, bv.w, acc[0][3]); acc[1][3] = MFMA16(x1, bv.w, acc[1][3]);
+    }
+  }
+  float* dst = dPool + (size_t)ent.pool[e] * IO + col0 + 4 * j;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dd = 16 * r + 4 * kq + q;
+      if (dd < d)
+        *reinterpret_cast<float4*>(dst + (size_t)dd * Kt * IO) =
+            make_float4(acc[r][0][q], acc[r][1][q], acc[r][2][q], acc[r][3][q]);
+    }
+}
+
+// (2) TmpK[e][n][dd] += sum_io dWp[n][slot(e)][io] * Wpool[dd][pool(e)][io]
+//     A = dWp (rows n, reduction io), B = Wpool^T: both lie K-contiguous, so a lane's float4 is four MFMA steps of its
+//     row (the node kernels' operand trick).  One wave per (entry, 16 nodes, 1/splits of the io range), fp32 atomics.
+__global__ __launch_bounds__(256) void k_pool_emb_mfma(const float* __restrict__ dWp, const float* __restrict__ wpool,
+                                                       StackEntries ent, int N, int d, long IO, int S, int Kt, int splits,
+                                                       float* __restrict__ TmpK) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, j = lane & 15;
+  const int e = blockIdx.y;
+  const int tile = blockIdx.x / splits, part = (blockIdx.x - tile * splits) * 4 + (threadIdx.x >> 6), parts = splits * 4;
+  const long groups = IO >> 4, per = (groups + parts - 1) / parts;
+  const long g0 = part * per, g1 = min(g0 + per, groups);
+  const int node = min(tile * 16 + j, N - 1);
+  const float* ap = dWp + (size_t)node * S * IO + (size_t)ent.slot[e] * IO + 4 * kq;
+  const float* bp0 = wpool + ((size_t)min(j, d - 1) * Kt + ent.pool[e]) * IO + 4 * kq;
+  const float* bp1 = wpool + ((size_t)min(16 + j, d - 1) * Kt + ent.pool[e]) * IO + 4 * kq;
+  const bool ok0 = j < d, ok1 = 16 + j < d;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (long g = g0; g < g1; g += 2) {
+    const long gb = min(g + 1, g1 - 1);
+    const float4 a0 = *reinterpret_cast<const float4*>(ap + g * 16), a1 = *reinterpret_cast<const float4*>(ap + gb * 16);
+    float4 p0 = *reinterpret_cast<const float4*>(bp0 + g * 16), p1 = *reinterpret_cast<const float4*>(bp1 + g * 16);
+    float4 q0 = *reinterpret_cast<const float4*>(bp0 + gb * 16), q1 = *reinterpret_cast<const float4*>(bp1 + gb * 16);
+    if (!ok0) { p0 = make_float4(0.f, 0.f, 0.f, 0.f); q0 = p0; }
+    if (!ok1) { p1 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = p1; }
+    if (g + 1 >= g1) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
+    acc[0] = MFMA16(a0.x, p0.x, acc[0]); acc[1] = MFMA16(a0.x, p1.x, acc[1]);
+    acc[0] = MFMA16(a0.y, p0.y, acc[0]); acc[1] = MFMA16(a0.y, p1.y, acc[1]);
+    acc[0] = MFMA16(a0.z, p0.z, acc[0]); acc[1] = MFMA16(a0.z, p1.z, acc[1]);
+    acc[0] = MFMA16(a0.w, p0.w, acc[0]); acc[1] = MFMA16(a0.w, p1.w, acc[1]);
+    acc[0] = MFMA16(a1.x, q0.x, acc[0]); acc[1] = MFMA16(a1.x, q1.x, acc[1]);
+    acc[0] = MFMA16(a1.y, q0.y, acc[0]); acc[1] = MFMA16(a1.y, q1.y, acc[1]);
+    acc[0] = MFMA16(a1.z, q0.z, acc[0]); acc[1] = MFMA16(a1.z, q1.z, acc[1]);
+    acc[0] = MFMA16(a1.w, q0.w, acc[0]); acc[1] = MFMA16(a1.w, q1.w, acc[1]);
+  }
+  if (g0 >= g1) return;
+  float* dst = TmpK + (size_t)e * N * d;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = tile * 16 + 4 * kq + q, dd = 16 * r + j;
+      if (n < N && dd < d) unsafeAtomicAdd(dst + (size_t)n * d + dd, acc[r][q]);
+    }
+}
+
 // dE[n][d] += sum_e g_k(e) f_e[n] TmpK[e][n][d];   dgain[k(e)] += sum_{n,d} f_e[n] E[n][d] TmpK[e][n][d]
 __global__ __launch_bounds__(256) void k_emb_grad(const float* __restrict__ TmpK, const float* __restrict__ FK,
                                                   const float* __restrict__ E, const float* __restrict__ wg, int Kt,
@@ -1116,6 +1222,92 @@ __global__ __launch_bounds__(192 * WN_GROUPS) void k_wgrad_narrow(const float* _
     }
 }
 
+// The same gradients on the matrix cores (round 3; S * C0 <= 16).  Per node a [S*C0 x rows] . [rows x 192] product:
+// the (slot, channel) pairs are the 16 rows of ONE MFMA tile, the 192 gradient columns its 12 column tiles.  A lane's
+// float4 of a gradient row is the same column of FOUR column tiles (column 64 og + 4 (l & 15) + ct), so a step of four
+// rows is three 1 KB loads per wave feeding twelve MFMAs, eight steps in flight - bound by the 475 MB it streams instead
+// of by 48 dependent iterations per thread (0.30 ms alone, 1.0 ms beside the adjacency gradients in the tail of the
+// backward).  Waves = row streams (WNM_PARTS x 4 per node); the four of a workgroup meet in LDS, one atomic per output.
+#define WNM_PARTS 8
+template <int C0, int S>
+__global__ __launch_bounds__(256) void k_wgrad_narrow_mfma(const float* __restrict__ x0tm, const float* __restrict__ mx0,
+                                                           long ld, const float* __restrict__ dpg,
+                                                           const float* __restrict__ dpu, float* __restrict__ dWpG,
+                                                           float* __restrict__ dWpU, int T, int B, int N, int Np, int I) {
+  static_assert(S * C0 <= 16, "one MFMA row tile");
+  __shared__ float part[3][S * C0][192];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, kq = lane >> 4, j = lane & 15;
+  const int rows = T * B, stream = blockIdx.y * 4 + w, streams = WNM_PARTS * 4;
+  const int steps = (rows + 3) >> 2, per = (steps + streams - 1) / streams;
+  const int st0 = stream * per, st1 = min(st0 + per, steps);
+  const int sl = j / C0, ch = j - sl * C0;          // this lane's A row: (slot, channel)
+  const bool aLive = j < S * C0;
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int og = 0; og < 3; ++og)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[og][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int st, float4 (&bv)[3], float& av) {
+    const int r = 4 * st + kq, rc = min(r, rows - 1);
+    const size_t rowN = (size_t)rc * Np + n;
+    bv[0] = *reinterpret_cast<const float4*>(dpg + rowN * 128 + 4 * j);
+    bv[1] = *reinterpret_cast<const float4*>(dpg + rowN * 128 + 64 + 4 * j);
+    bv[2] = *reinterpret_cast<const float4*>(dpu + rowN * 64 + 4 * j);
+    const int t = rc / B, b = rc - t * B;
+    const float* src = sl == 0 ? x0tm + rowN * C0 + ch
+                               : mx0 + (size_t)(sl - 1) * Np * ld + (size_t)n * ld + ((size_t)b * T + t) * C0 + ch;
+    const float v = aLive ? *src : 0.f;
+    av = r < rows ? v : 0.f;
+  };
+  constexpr int DEPTH = 4;
+  float4 bq[DEPTH][3];
+  float aq[DEPTH];
+  if (st0 < st1) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) load(min(st0 + u, st1 - 1), bq[u], aq[u]);
+    for (int st = st0; st < st1; st += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const float4 b0 = bq[u][0], b1 = bq[u][1], b2 = bq[u][2];
+        const float a = st + u < st1 ? aq[u] : 0.f;
+        load(min(st + u + DEPTH, st1 - 1), bq[u], aq[u]);
+        acc[0][0] = MFMA16(a, b0.x, acc[0][0]); acc[0][1] = MFMA16(a, b0.y, acc[0][1]);
+        acc[0][2] = MFMA16(a, b0.z, acc[0][2]); acc[0][3] = MFMA16(a, b0.w, acc[0][3]);
+        acc[1][0] = MFMA16(a, b1.x, acc[1][0]); acc[1][1] = MFMA16(a, b1.y, acc[1][1]);
+        acc[1][2] = MFMA16(a, b1.z, acc[1][2]); acc[1][3] = MFMA16(a, b1.w, acc[1][3]);
+        acc[2][0] = MFMA16(a, b2.x, acc[2][0]); acc[2][1] = MFMA16(a, b2.y, acc[2][1]);
+        acc[2][2] = MFMA16(a, b2.z, acc[2][2]); acc[2][3] = MFMA16(a, b2.w, acc[2][3]);
+      }
+    }
+  }
+  // accumulator rows 4 kq + e = (slot, channel) pairs, column 64 og + 4 j + ct
+  if (w > 0) {
+#pragma unroll
+    for (int og = 0; og < 3; ++og)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * kq + e < S * C0) part[w - 1][4 * kq + e][64 * og + 4 * j + ct] = acc[og][ct][e];
+  }
+  __syncthreads();
+  if (w > 0) return;
+#pragma unroll
+  for (int og = 0; og < 3; ++og)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = 4 * kq + e;
+        if (m >= S * C0) continue;
+        const int o = 64 * og + 4 * j + ct;
+        const float v = acc[og][ct][e] + part[0][m][o] + part[1][m][o] + part[2][m][o];
+        const int s2 = m / C0, c2 = m - s2 * C0;
+        if (og < 2) unsafeAtomicAdd(&dWpG[(((size_t)n * S + s2) * I + c2) * 128 + o], v);
+        else unsafeAtomicAdd(&dWpU[(((size_t)n * S + s2) * I + c2) * 64 + (o - 128)], v);
+      }
+}
+
 // ---- x-column gradients of layer 0's NARROW input (the transposed counterpart of k_wgrad_narrow) -----------------
 //   dA[s][n][row][c] = sum_o dpg[row][n][o] WpG[n][s][c][o] + sum_o dpu[row][n][o] WpU[n][s][c][o]        (c < C0)
 // node-major output (the transposed mix then is ONE GEMM with rows*C0 columns).  As a GEMM this has N = C0 output
@@ -1154,6 +1346,111 @@ __global__ __launch_bounds__(256) void k_xcol_narrow(const float* __restrict__ d
   for (int sl = 0; sl < S; ++sl)
 #pragma unroll
     for (int c = 0; c < C0; ++c) dA[(((size_t)sl * Np + n) * rows + row) * C0 + c] = acc[sl * C0 + c];
+}
+
+// ---- x columns of the residual cell for a NARROW input (layer 0) ---------------------------------------------------
+//   dX[row][c] += sum_o dpu2[row][o] RU[o][c] + sum_o dpg2[row][o] RG[o][c]        (c < C0; RU (64, I), RG (128, I))
+// As GEMMs these have N = C0 output columns (two launches of the generic kernel, 0.40 ms of 97 % padding on the main
+// stream, in the tail of the backward).  Here the 192 pre-activation gradients of a row stream through once, coalesced:
+// 16 lanes share a row (three float4 each), every lane keeps its 12 x C0 weights in registers, the 16 partial sums
+// meet in a butterfly.  Bound by the 768 bytes per row it reads.
+template <int C0>
+__global__ __launch_bounds__(256) void k_res_xcol_narrow(const float* __restrict__ dpu2, const float* __restrict__ dpg2,
+                                                         const float* __restrict__ RU, const float* __restrict__ RG, int I,
+                                                         float* __restrict__ dX, long rows) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, rw = lane >> 4;
+  float wu[4][C0], wg[8][C0];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+      wu[e][c] = RU[(size_t)(4 * sub + e) * I + c];
+      wg[e][c] = RG[(size_t)(4 * sub + e) * I + c];
+      wg[4 + e][c] = RG[(size_t)(64 + 4 * sub + e) * I + c];
+    }
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (long)gridDim.x * 4;
+  for (long r0 = wave * 4; r0 < rows; r0 += waves * 4) {
+    const long row = min(r0 + rw, rows - 1);
+    const float4 u = *reinterpret_cast<const float4*>(dpu2 + row * 64 + 4 * sub);
+    const float4 ga = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 4 * sub);
+    const float4 gb = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 64 + 4 * sub);
+    float acc[C0];
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+      float v = u.x * wu[0][c];
+      v = fmaf(u.y, wu[1][c], v); v = fmaf(u.z, wu[2][c], v); v = fmaf(u.w, wu[3][c], v);
+      v = fmaf(ga.x, wg[0][c], v); v = fmaf(ga.y, wg[1][c], v); v = fmaf(ga.z, wg[2][c], v); v = fmaf(ga.w, wg[3][c], v);
+      v = fmaf(gb.x, wg[4][c], v); v = fmaf(gb.y, wg[5][c], v); v = fmaf(gb.z, wg[6][c], v); v = fmaf(gb.w, wg[7][c], v);
+      acc[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) acc[c] += __shfl_xor(acc[c], m, 16);
+    }
+    if (sub == 0 && r0 + rw < rows) {
+#pragma unroll
+      for (int c = 0; c < C0; ++c) dX[(r0 + rw) * C0 + c] += acc[c];
+    }
+  }
+}
+
+// ---- residual nn.Linear weight gradients of a NARROW input's columns (layer 0) ---------------------------------------
+//   dRG[o][c] += sum_rows dpg2[row][o] x[row][c]   (o < 128),   dRU[o][c] += sum_rows dpu2[row][o] x[row][c]   (o < 64)
+// As GEMMs: N = C0 columns, 2 x 0.25 ms of the generic kernel.  The lane map of k_res_xcol_narrow: 16 lanes share a row,
+// 12 gradient columns per lane, C0 accumulators each; the partial sums of a workgroup meet in LDS and leave as one
+// atomic add per (o, c).
+template <int C0>
+__global__ __launch_bounds__(256) void k_res_wgrad_narrow(const float* __restrict__ dpu2, const float* __restrict__ dpg2,
+                                                          const float* __restrict__ x, int I, float* __restrict__ dRU,
+                                                          float* __restrict__ dRG, long rows) {
+  __shared__ float part[4][192 * C0];
+  const int lane = threadIdx.x & 63, sub = lane & 15, rw = lane >> 4, w = threadIdx.x >> 6;
+  float acc[12][C0];
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) acc[i][c] = 0.f;
+  const long wave = (long)blockIdx.x * 4 + w, waves = (long)gridDim.x * 4;
+  for (long r0 = wave * 4; r0 < rows; r0 += waves * 4) {
+    const long row = min(r0 + rw, rows - 1);
+    const float live = r0 + rw < rows ? 1.f : 0.f;
+    const float4 u = *reinterpret_cast<const float4*>(dpu2 + row * 64 + 4 * sub);
+    const float4 ga = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 4 * sub);
+    const float4 gb = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 64 + 4 * sub);
+    const float d[12] = {u.x, u.y, u.z, u.w, ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+      const float xv = x[row * C0 + c] * live;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc[i][c] = fmaf(d[i], xv, acc[i][c]);
+    }
+  }
+  // the four rows of a wave, then the four waves
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int c = 0; c < C0; ++c) {
+      float v = acc[i][c];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      acc[i][c] = v;
+    }
+  // slot of gradient column i of this lane: 0..63 dpu2 column 4 sub + e, 64..191 dpg2 column
+  if (rw == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int o = i < 4 ? 4 * sub + i : (i < 8 ? 64 + 4 * sub + (i - 4) : 128 + 4 * sub + (i - 8));
+#pragma unroll
+      for (int c = 0; c < C0; ++c) part[w][o * C0 + c] = acc[i][c];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 192 * C0; e += 256) {
+    const float v = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+    const int o = e / C0, c = e - o * C0;
+    if (o < 64) unsafeAtomicAdd(dRU + (size_t)o * I + c, v);
+    else unsafeAtomicAdd(dRG + (size_t)(o - 64) * I + c, v);
+  }
 }
 
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
