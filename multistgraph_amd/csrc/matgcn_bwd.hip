@@ -1023,7 +1023,11 @@ int bwd_pools_layer(Pass& pass, int l, hipStream_t onStream) {
         hipLaunchKernelGGL(k_softmax_bwd_small, dim3(1), dim3(64), 0, s, ap.weights_g, dgain, Kt, ag.weights_g);
         CHECK_LAUNCH();
       }
-      {  // bias = E . bias_pool
+      if (O == 64 || O == 128) {   // bias = E . bias_pool: both gradients in one small launch
+        hipLaunchKernelGGL(k_bias_pool_grad, dim3((unsigned)(P.d + blocks_for((size_t)N * P.d))), dim3(256), 0, s,
+                           prm->node_emb, dBias, ap.bias_pool, N, P.d, O, ag.bias_pool, g->node_emb);
+        CHECK_LAUNCH();
+      } else {
         GemmArgs q = gemm_args(prm->node_emb, dBias, ag.bias_pool, P.d, O, N);
         q.sAm = 1; q.sAk = P.d; q.sBk = O; q.sBn = 1; q.sCm = O; q.sCn = 1;
         RETURN_IF(gemm(q, 1, s));
@@ -1213,7 +1217,9 @@ static int forward_train_impl(const matgcn_dims* dims, const matgcn_params* para
   if (!prepared || (!X && !src) || !out || !train) return MATGCN_ERR_NULL;
   if (src) RETURN_IF(check_series(dims, src->series, src->series_steps, src->label_start, src->rel_steps));
   Ctx c;
-  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));
+  // (a lazy matgcn_prepare: the encoder's chains wait for the weight streams they read, as in the inference forward;
+  // what the side stream below reads of `prepared` - the support stack - was written on the caller's stream)
+  RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream, false));
   if (!params->weight_tsg || !params->end_conv_bias) return MATGCN_ERR_NULL;
   for (int h = 0; h < dims->n_heads; ++h) if (!params->weight_ts[h]) return MATGCN_ERR_NULL;
   RETURN_IF(check_layer_params(dims, params));

@@ -513,6 +513,39 @@ __global__ __launch_bounds__(256) void k_pool_emb_mfma(const float* __restrict__
     }
 }
 
+// bias = E . bias_pool (MultiATGCN.py:105), both gradients in one launch (two 64 x 64-tile GEMMs of M = d resp. N = d
+// took 70-120 us per AGCN):  dBpool[dd][o] = sum_n E[n][dd] dBias[n][o]  (blocks 0 .. d-1: block dd, thread o, four
+// partial sums over the nodes);  dE[n][dd] += sum_o dBias[n][o] bpool[dd][o]  (the remaining blocks: one thread per (n, dd))
+__global__ __launch_bounds__(256) void k_bias_pool_grad(const float* __restrict__ E, const float* __restrict__ dBias,
+                                                        const float* __restrict__ bpool, int N, int d, int O,
+                                                        float* __restrict__ dBpool, float* __restrict__ dE) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < d) {
+    const int dd = blockIdx.x, o = threadIdx.x % O, part = threadIdx.x / O, parts = 256 / O;
+    float s = 0.f;
+    for (int n = part; n < N; n += parts) s = fmaf(E[(size_t)n * d + dd], dBias[(size_t)n * O + o], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0) {
+      for (int q = 1; q < parts; ++q) s += red[q * O + o];
+      dBpool[(size_t)dd * O + o] = s;
+    }
+    return;
+  }
+  if (!dE) return;
+  const int idx = (blockIdx.x - d) * 256 + threadIdx.x;
+  if (idx >= N * d) return;
+  const int n = idx / d, dd = idx - n * d;
+  const float4* a = reinterpret_cast<const float4*>(dBias + (size_t)n * O);
+  const float4* b = reinterpret_cast<const float4*>(bpool + (size_t)dd * O);
+  float s = 0.f;
+  for (int q = 0; q < O / 4; ++q) {
+    const float4 x = a[q], y = b[q];
+    s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+  }
+  dE[idx] += s;
+}
+
 // dE[n][d] += sum_e g_k(e) f_e[n] TmpK[e][n][d];   dgain[k(e)] += sum_{n,d} f_e[n] E[n][d] TmpK[e][n][d]
 __global__ __launch_bounds__(256) void k_emb_grad(const float* __restrict__ TmpK, const float* __restrict__ FK,
                                                   const float* __restrict__ E, const float* __restrict__ wg, int Kt,

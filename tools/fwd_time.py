@@ -52,7 +52,7 @@ def main():
                                                     for k, v in sorted(ser.items()))
         line += "   serial sum %.2f ms" % (sum(sum(v) for v in ser.values()) / 2)
     if args.train:
-        t = bench.train_step_times(model, batch, w, warm=3, steps=8)
+        t = bench.train_step_times(model, batch, w, warm=3, steps=int(os.environ.get("TRAIN_STEPS", "8")))
         line += "   train: fwd %.2f bwd %.2f step %.2f ms" % (t["forward_ms"], t["backward_ms"], t["ms_per_step"])
     print(line, flush=True)
 
