@@ -402,8 +402,17 @@ int plain_operands(const Ctx& c, float* tr, hipStream_t s) {
       q.E = c.prm->node_emb; q.wpool = ap.weights_pool; q.wg = c.D->scale_by_g ? ap.weights_g : nullptr;
       q.out = tr + R.oWp[l][part];
       q.d = P.d; q.I = P.Cl[l] + H; q.O = part == 0 ? 128 : 64; q.N = P.N; q.S = R.S; q.map = map;
-      hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for((size_t)R.S * q.I * q.O), (unsigned)((P.N + PP_NODES - 1) / PP_NODES)),
-                         dim3(256), 0, s, q);
+      const size_t perNode = (size_t)R.S * q.I * q.O;
+      if (P.d <= 32 && perNode % 16 == 0) {   // the embedding contraction on the matrix cores (k_prep_mfma's, plain layout)
+        const int nTiles = (P.N + 15) / 16, tilesPerBlock = 16;
+        const dim3 grid((unsigned)((perNode + 127) / 128), (unsigned)((nTiles + tilesPerBlock - 1) / tilesPerBlock));
+        if (P.d <= 12) hipLaunchKernelGGL(k_prep_plain_mfma<3>, grid, dim3(256), 0, s, q, tilesPerBlock);
+        else if (P.d <= 20) hipLaunchKernelGGL(k_prep_plain_mfma<5>, grid, dim3(256), 0, s, q, tilesPerBlock);
+        else hipLaunchKernelGGL(k_prep_plain_mfma<8>, grid, dim3(256), 0, s, q, tilesPerBlock);
+      } else {
+        hipLaunchKernelGGL(k_prep_plain, dim3(blocks_for(perNode), (unsigned)((P.N + PP_NODES - 1) / PP_NODES)), dim3(256),
+                           0, s, q);
+      }
       CHECK_LAUNCH();
     }
   return MATGCN_OK;

@@ -407,6 +407,108 @@ __global__ __launch_bounds__(256) void k_scaled_emb(const float* __restrict__ E,
   if (idx % d == 0) FK[(size_t)e * map.N + n] = f;
 }
 
+// The same plain weights on the matrix cores (round 3; the embedding contraction of k_prep_mfma with another choice of
+// the 16 A rows): a quad is 16 consecutive output columns o of ONE weight row (s, i), so the accumulator of a lane - rows
+// 4 (l >> 4) + e, column l & 15 - is a float4 of four consecutive o for node l & 15, stored straight into [n][s][i][o].
+// A wave keeps 8 quads (128 consecutive elements of the [S*I][O] matrix) and walks 16-node tiles.  The stack gain is
+// folded into the A values as the forward's weight streams have it, so both hold the same numbers.
+template <int DS>
+__global__ __launch_bounds__(256) void k_prep_plain_mfma(PlainPrep a, int tilesPerBlock) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, ka = lane >> 4;
+  const size_t per = (size_t)a.S * a.I * a.O;
+  const size_t base = (size_t)blockIdx.x * 128;
+  const size_t dstride = (size_t)a.map.KtotOrig * a.I * a.O;
+  float A[8][DS], Aq[8][DS];
+  bool ident = false;
+#pragma unroll
+  for (int q8 = 0; q8 < 8; ++q8) {
+    const size_t el = min(base + 16 * q8 + r, per - 1);
+    const int o = (int)(el % a.O), row = (int)(el / a.O), i = row % a.I, sl = row / a.I;
+    const int k = a.map.keepK[sl];
+    const float gain = stack_gain(a.wg, a.map.KtotOrig, k);
+    const float* src = a.wpool + ((size_t)k * a.I + i) * a.O + o;
+    const bool id = sl == 0 && a.map.nDiag > 0;
+    ident = ident || id;
+    const float* srcq = a.wpool + ((size_t)a.map.diagK[0] * a.I + i) * a.O + o;
+#pragma unroll
+    for (int st = 0; st < DS; ++st) {
+      const int dd = 4 * st + ka;
+      const float v = src[(size_t)min(dd, a.d - 1) * dstride];
+      A[q8][st] = dd < a.d ? v * gain : 0.f;
+      const float vq = id ? srcq[(size_t)min(dd, a.d - 1) * dstride] : 0.f;
+      Aq[q8][st] = (dd < a.d && id) ? vq : 0.f;
+    }
+  }
+  const bool anyIdent = __ballot(ident) != 0ull;
+  const int nTiles = (a.N + 15) >> 4;
+  const int tile0 = blockIdx.y * tilesPerBlock, tile1 = min(tile0 + tilesPerBlock, nTiles);
+  const int nodeL = lane & 15, kb = lane >> 4;
+  auto load_b = [&](int tile, float (&Bf)[DS]) {
+    const float* e = a.E + (size_t)min(tile * 16 + nodeL, a.N - 1) * a.d;
+#pragma unroll
+    for (int st = 0; st < DS; ++st) {
+      const int dd = 4 * st + kb;
+      const float v = e[min(dd, a.d - 1)];
+      Bf[st] = dd < a.d ? v : 0.f;
+    }
+  };
+  float Bf[DS], Bn[DS];
+  if (tile0 + w < tile1) load_b(tile0 + w, Bf);
+  for (int tile = tile0 + w; tile < tile1; tile += 4) {
+    load_b(min(tile + 4, tile1 - 1), Bn);
+    const int n = tile * 16 + nodeL;
+    f32x4 acc[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) acc[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < DS; ++st)
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) acc[q8] = MFMA16(A[q8][st], Bf[st], acc[q8]);
+    if (anyIdent) {
+      const int nc = min(n, a.N - 1);
+      for (int q = 0; q < a.map.nDiag; ++q) {
+        f32x4 part[8];
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) part[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q == 0) {
+#pragma unroll
+          for (int st = 0; st < DS; ++st)
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) part[q8] = MFMA16(Aq[q8][st], Bf[st], part[q8]);
+        } else {   // further diagonal supports: their pool values are re-read (rare)
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) {
+            const size_t el = min(base + 16 * q8 + r, per - 1);
+            const int o = (int)(el % a.O), row = (int)(el / a.O), i = row % a.I, sl = row / a.I;
+#pragma unroll
+            for (int st = 0; st < DS; ++st) {
+              const int dd = 4 * st + ka;
+              const float v = a.wpool[(size_t)min(dd, a.d - 1) * dstride + ((size_t)a.map.diagK[q] * a.I + i) * a.O + o];
+              part[q8] = MFMA16((dd < a.d && sl == 0) ? v : 0.f, Bf[st], part[q8]);
+            }
+          }
+        }
+        const float t = stack_gain(a.wg, a.map.KtotOrig, a.map.diagK[q]) *
+                        cheb_scalar(a.map.diagSrc[q][(size_t)nc * (a.map.N + 1)], a.map.diagOrder[q]);
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[q8][e] = fmaf(t, part[q8][e], acc[q8][e]);
+      }
+    }
+    if (n < a.N) {
+      float* dst = a.out + (size_t)n * per + base + 4 * kb;
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8)
+        if (base + 16 * q8 + 4 * kb < per)
+          *reinterpret_cast<float4*>(dst + 16 * q8) = make_float4(acc[q8][0], acc[q8][1], acc[q8][2], acc[q8][3]);
+    }
+#pragma unroll
+    for (int st = 0; st < DS; ++st) Bf[st] = Bn[st];
+  }
+}
+
 // ---- the two pool-gradient products on the matrix cores (round 3) ---------------------------------------------------
 // Both have the embedding dimension d (<= 32) as one side of the product: on 64 x 64 GEMM tiles (k_bgemm<BG_POOL>) two
 // thirds of every tile were padding and the plain weight gradients dWp (250 MB per backward) streamed through the scalar
