@@ -267,6 +267,21 @@ int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int C
   const int S = b.c.R.S;
   for (int j = 0; j < P.per; ++j) {
     const size_t slot = nodeMajor ? (size_t)(1 + j) * P.Np * rows * Cc : (size_t)(1 + j) * P.Np * Cc;
+#ifndef ADJ_LAB_GENERIC
+    if (!nodeMajor && Cc == H && rows >= 8) {   // both operands in 256-byte node rows: the dedicated kernel (k_adj_grad)
+      AdjGradArgs q;
+      q.A = dA + slot; q.B = U; q.aStride = (long)S * P.Np * H; q.bStride = (long)P.Np * H;
+      q.R = rows; q.N = P.N; q.Np = P.Np; q.dT = dT + (size_t)j * P.N * P.N;
+      const unsigned tiles = (unsigned)((P.Np + 63) / 64);
+      // one resident set of workgroups (5 per CU at 32 KB of LDS): 1 280 / tiles^2 slices of the row blocks
+      int split = (int)(1280 / (tiles * tiles));
+      if (split < 1) split = 1;
+      if (split > rows) split = rows;
+      hipLaunchKernelGGL(k_adj_grad, dim3(tiles, tiles, (unsigned)split), dim3(256), 0, b.c.s, q);
+      CHECK_LAUNCH();
+      continue;
+    }
+#endif
     GemmArgs g = gemm_args(dA + slot, U, dT + (size_t)j * P.N * P.N, P.N, P.N, Cc);
     g.K2 = rows;
     g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;

@@ -1297,6 +1297,106 @@ __global__ __launch_bounds__(S * O, MINW) void k_wgrad_node(WgradNodeArgs a) {
           unsafeAtomicAdd(dst + (size_t)(16 * mt + 4 * kq + e) * O + 16 * nt, acc[mt][nt][e]);
 }
 
+// ---- gradient of the learned support (round 3): dT[n][m] += sum_r sum_i dA[r][n][i] * U[r][m][i] -------------------
+// Both operands are [rows][nodes][64] blocks with the reduction index i CONTIGUOUS (a node's 256-byte row): for the
+// 16x16x4 fp32 MFMA a lane's float4 of its row IS four reduction steps (the node kernels' operand trick), for the A and
+// for the B side alike - nothing has to be transposed on the way.  The generic GEMM turned both tiles into k-major LDS
+// images first (scalar LDS stores, 51 % MFMA busy, 470 us for 32 GFLOP); here a 64-node x 32-i half of a row block goes
+// from global memory to LDS as whole float4s (16-byte slots XOR-swizzled by the row) and comes back as ds_read_b128
+// fragments: 32 MFMAs per wave and stage behind 8 LDS reads.  64 x 64 output tiles, 2 x 2 MFMA tiles per wave; the
+// 32-row halves of the last tile that lie beyond the padded node count are skipped (403 nodes: 6.5 x 6.5 tiles of work
+// instead of 7 x 7); split over the row blocks, fp32 atomics into dT.
+struct AdjGradArgs {
+  const float* A;        // dA + slot offset: row block r at A + r * aStride, node n at + n * 64
+  const float* B;        // U: row block r at B + r * bStride
+  long aStride, bStride;
+  int R, N, Np;          // row blocks, nodes, padded nodes (rows of a block that exist)
+  float* dT;             // [N][N]
+};
+
+__global__ __launch_bounds__(256) void k_adj_grad(AdjGradArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][64 * 32];
+  __shared__ __attribute__((aligned(16))) float Bs[2][64 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int wr = w >> 1, wc = w & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int per = (g.R + gridDim.z - 1) / gridDim.z;
+  const int r0 = blockIdx.z * per, r1 = min(r0 + per, g.R);
+  if (r0 >= r1) return;
+  const bool live = m0 + wr * 32 < g.Np && n0 + wc * 32 < g.Np;     // wave-uniform
+  // staging: thread -> rows (tid >> 3) and (tid >> 3) + 32 of the tile, 16-byte slot tid & 7 of the 32-i half
+  const int srow = tid >> 3, sq = tid & 7;
+  const size_t aOff0 = (size_t)min(m0 + srow, g.Np - 1) * 64 + sq * 4, aOff1 = (size_t)min(m0 + srow + 32, g.Np - 1) * 64 + sq * 4;
+  const size_t bOff0 = (size_t)min(n0 + srow, g.Np - 1) * 64 + sq * 4, bOff1 = (size_t)min(n0 + srow + 32, g.Np - 1) * 64 + sq * 4;
+  const int st0 = (srow * 8 + (sq ^ (srow & 7))) * 4, st1 = ((srow + 32) * 8 + (sq ^ (srow & 7))) * 4;
+  const int stages = 2 * (r1 - r0);
+  struct Stage { float4 a0, a1, b0, b1; };
+  auto fetch = [&](int st) {
+    const int sc = min(st, stages - 1);
+    const size_t r = (size_t)(r0 + (sc >> 1)), h = (size_t)(sc & 1) * 32;
+    Stage v;
+    v.a0 = *reinterpret_cast<const float4*>(g.A + r * g.aStride + aOff0 + h);
+    v.a1 = *reinterpret_cast<const float4*>(g.A + r * g.aStride + aOff1 + h);
+    v.b0 = *reinterpret_cast<const float4*>(g.B + r * g.bStride + bOff0 + h);
+    v.b1 = *reinterpret_cast<const float4*>(g.B + r * g.bStride + bOff1 + h);
+    return v;
+  };
+  auto stash = [&](int buf, const Stage& v) {
+    *reinterpret_cast<float4*>(&As[buf][st0]) = v.a0;
+    *reinterpret_cast<float4*>(&As[buf][st1]) = v.a1;
+    *reinterpret_cast<float4*>(&Bs[buf][st0]) = v.b0;
+    *reinterpret_cast<float4*>(&Bs[buf][st1]) = v.b1;
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Stage cur = fetch(0);
+  stash(0, cur);
+  cur = fetch(1);         // stage 1 waits in `cur`, stage 2 in `nxt`
+  Stage nxt = fetch(2);
+  __syncthreads();
+  // fragment rows of this wave: A rows wr*32 + 16 p + j, B rows wc*32 + 16 q + j; slot 4 gq + kq, swizzled by the row
+  const int ra0 = wr * 32 + j, ra1 = ra0 + 16, rb0 = wc * 32 + j, rb1 = rb0 + 16;
+  for (int st = 0; st < stages; ++st) {
+    const int buf = st & 1;
+    // stage st + 1 into the other buffer (its last readers passed the barrier at the end of stage st - 1)
+    stash(buf ^ 1, cur);
+    cur = nxt;
+    nxt = fetch(st + 3);
+    if (live) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        const int sl = 4 * gq + kq;
+        const float4 a0 = *reinterpret_cast<const float4*>(&As[buf][(ra0 * 8 + (sl ^ (ra0 & 7))) * 4]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&As[buf][(ra1 * 8 + (sl ^ (ra1 & 7))) * 4]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&Bs[buf][(rb0 * 8 + (sl ^ (rb0 & 7))) * 4]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&Bs[buf][(rb1 * 8 + (sl ^ (rb1 & 7))) * 4]);
+        acc[0][0] = MFMA16(a0.x, b0.x, acc[0][0]); acc[0][1] = MFMA16(a0.x, b1.x, acc[0][1]);
+        acc[1][0] = MFMA16(a1.x, b0.x, acc[1][0]); acc[1][1] = MFMA16(a1.x, b1.x, acc[1][1]);
+        acc[0][0] = MFMA16(a0.y, b0.y, acc[0][0]); acc[0][1] = MFMA16(a0.y, b1.y, acc[0][1]);
+        acc[1][0] = MFMA16(a1.y, b0.y, acc[1][0]); acc[1][1] = MFMA16(a1.y, b1.y, acc[1][1]);
+        acc[0][0] = MFMA16(a0.z, b0.z, acc[0][0]); acc[0][1] = MFMA16(a0.z, b1.z, acc[0][1]);
+        acc[1][0] = MFMA16(a1.z, b0.z, acc[1][0]); acc[1][1] = MFMA16(a1.z, b1.z, acc[1][1]);
+        acc[0][0] = MFMA16(a0.w, b0.w, acc[0][0]); acc[0][1] = MFMA16(a0.w, b1.w, acc[0][1]);
+        acc[1][0] = MFMA16(a1.w, b0.w, acc[1][0]); acc[1][1] = MFMA16(a1.w, b1.w, acc[1][1]);
+      }
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wr * 32 + 16 * p + 4 * kq + e, n = n0 + wc * 32 + 16 * q + j;
+        if (m < g.N && n < g.N) unsafeAtomicAdd(g.dT + (size_t)m * g.N + n, acc[p][q][e]);
+      }
+}
+
 // ---- node-adaptive weight gradients of layer 0's NARROW x rows (C0 = 2..16 input channels) ------------------------
 //   dWpG[n][s][c][o] += sum_rows XA[rows][n][s][c] * dpg[rows][n][o]      (o < 128; dWpU with dpu alike)
 // XA slot 0 = the input rows themselves (time-major x0), slots 1.. = the fold's plain matrix MX0 [(k, n)][ld] with
