@@ -363,11 +363,13 @@ struct LayerBufs {
 int bwd_clear(Pass& pass) {
   PASS_LOCALS(pass);
   // (only what is accumulated into, or what the GEMMs leave untouched: the rows of the padding nodes)
+  // (the accumulators of the node-adaptive weight gradients - 250 MB - are written and read on the weight-gradient
+  // stream only: cleared there, behind its fork, instead of in front of the first chain)
   for (int l = 0; l < P.L; ++l)
     for (int part = 0; part < 2; ++part) {
       const long O = part == 0 ? 128 : 64, I = P.Cl[l] + H;
-      RETURN_IF(zero_async(tr + R.oDWp[l][part], (long)N * S * I * O, s));
-      RETURN_IF(zero_async(tr + R.oDBias[l][part], (long)N * O, s));
+      RETURN_IF(zero_async(tr + R.oDWp[l][part], (long)N * S * I * O, ws));
+      RETURN_IF(zero_async(tr + R.oDBias[l][part], (long)N * O, ws));
     }
   if (hT < T) {
     RETURN_IF(zero_async(tr + R.oDSeq[0], (long)T * slab, s));
@@ -378,15 +380,16 @@ int bwd_clear(Pass& pass) {
   }
   for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) RETURN_IF(zero_async(tr + R.oMixOut[q], slab * (P.Ks > 1 ? P.Ks : 1), s));
   RETURN_IF(zero_async(tr + R.oDT, (long)P.per * N * N, s));
-  if (Np != N)
+  if (Np != N) {   // one launch for the padding rows of both scratch sets
+    PadRowBufs bufs;
+    int nb = 0;
     for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
-      float* padded[3] = {tr + R.oDAg[q], tr + R.oDAu[q], tr + R.oDAx[q]};
-      for (float* buf : padded) {
-        hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H)), dim3(256), 0, s, buf,
-                           rowsTB * S, N, Np, H);
-        CHECK_LAUNCH();
-      }
+      bufs.p[nb++] = tr + R.oDAg[q]; bufs.p[nb++] = tr + R.oDAu[q]; bufs.p[nb++] = tr + R.oDAx[q];
     }
+    hipLaunchKernelGGL(k_zero_pad_rows_multi, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H / 4), (unsigned)nb),
+                       dim3(256), 0, s, bufs, rowsTB * S, N, Np, H);
+    CHECK_LAUNCH();
+  }
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
   RETURN_IF(zero_grad(g->weights_gru, (long)P.L * T));
@@ -457,14 +460,22 @@ int bwd_head(Pass& pass, const float* dOut) {
       q.scaleC = b.dropMask; q.bS1 = (long)N * H; q.bS2 = (long)hT * N * H; q.sSm = H; q.sSn = 1;
     }
     RETURN_IF(gemm(q, hT, s, BG_HEAD));
-    RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * hT * H, s));
+    // the head's weight gradient feeds nothing in this pass: with two streams it runs on the second one (behind the
+    // operand preparation, joined with the last layer's weight gradients) instead of in front of the first chain
+    hipStream_t hs = s;
+    if (pass.twoStreams) {
+      HIP_OK(hipEventRecord(g_wf.auxFork, s));          // dOutRows is there
+      HIP_OK(hipStreamWaitEvent(pass.ws, g_wf.auxFork, 0));
+      hs = pass.ws;
+    }
+    RETURN_IF(zero_async(g->end_conv_weight, (long)P.CH * hT * H, hs));
     GemmArgs w = gemm_args(dOutRows, seqTop + (size_t)tOff * slab, g->end_conv_weight, P.CH, H, N);
     w.K2 = B;
     w.sAm = 1; w.sAk = P.CH; w.sAk2 = (long)Np * P.CH;
     w.sBk = H; w.sBn = 1; w.sBk2 = (long)Np * H; w.bB1 = slab;
     w.sCm = (long)hT * H; w.sCn = 1; w.bC1 = H;
     w.mode = 1; w.split = 16;
-    RETURN_IF(gemm(w, hT, s, BG_HEAD));
+    RETURN_IF(gemm(w, hT, hs, BG_HEAD));
   }
 
   return MATGCN_OK;

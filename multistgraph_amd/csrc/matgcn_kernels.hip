@@ -493,6 +493,18 @@ __global__ __launch_bounds__(256) void k_zero_pad_rows(float* __restrict__ buf, 
   buf[(r * Np + N) * C + q] = 0.f;
 }
 
+// the same for up to 8 buffers of one shape in ONE launch (blockIdx.y picks the buffer), 16 bytes per thread (C % 4 == 0):
+// the backward opens with six of them in front of its first chain
+struct PadRowBufs { float* p[8]; };
+__global__ __launch_bounds__(256) void k_zero_pad_rows_multi(PadRowBufs bufs, int rows, int N, int Np, int C) {
+  const int per4 = (Np - N) * C / 4;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)rows * per4) return;
+  const size_t r = idx / per4;
+  const int q = (int)(idx - r * per4);
+  *reinterpret_cast<float4*>(bufs.p[blockIdx.y] + (r * Np + N) * C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // =================================================================================================
 // 4. temporal-head fusion prologue (MultiATGCN.py:365-402)
 // =================================================================================================

@@ -470,6 +470,9 @@ def test_full_size_directional_derivative(lib_built):
     # day + 7 day-of-week channels + 5 dynamic variables = 14 input channels
     (21, 2, 2, {"ext": 13}),
     (16, 3, 1, {"ext": 0}),         # add_time_in_day off: the flow channel alone
+    # node embeddings of other widths than the default 20 (run_model_parameter.py sweeps embed_dim): 8 and 24 take the
+    # 3- and 8-step instantiations of the matrix-core prepare / pool-gradient kernels, 40 the kernels for wide embeddings
+    (21, 2, 2, {"embed": 8}), (21, 3, 2, {"embed": 24}), (16, 2, 2, {"embed": 40}),
 ])
 def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags, lib_built):
     """N a multiple of 16 (no padding rows anywhere), a batch that is not a multiple of the 64-row tile, and 1 / 3 / 4
@@ -482,17 +485,18 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     cheb = flags.get("cheb_order", 2)
     adjtype, adpadj = flags.get("adjtype", "multi"), flags.get("adpadj", "unidirection")
     od, ext = flags.get("end_dim", 1), flags.get("ext", 1)
-    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext")}
+    emb = flags.get("embed", 20)
+    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext", "embed")}
     cfg = dict(input_window=24, output_window=6, add_time_in_day=ext > 0, add_day_in_week=ext in (8, 13),
                load_dynamic=ext == 13,
-               adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, embed_dim_node=20, embed_dim_adj=20, rnn_units=64,
+               adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, embed_dim_node=emb, embed_dim_adj=20, rnn_units=64,
                num_layers=layers, device=torch.device("cpu"), batch_size=b, start_dim=0, end_dim=od, **abl)
     df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=ext), output_dim=od, feature_dim=od + ext)
     mats = graph_prep.build_static_supports(df["adj_mx"], df["coordinate"], None, adjtype)
     use_static = adpadj == "none" or adjtype == "multi"
     st = torch.from_numpy(np.stack(mats, 0))
     shapes = syn.param_shapes(n, out_steps=6, feat_in=od + ext, out_dim=od, k_total=syn.k_total_for(adjtype, adpadj, cheb),
-                              layers=layers, **abl)
+                              layers=layers, embed_dim_node=emb, **abl)
     state_np = syn.closed_form_state(shapes, 3)
     x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=od + ext)
     if od > 1:   # channels [flow 0 .. flow od-1 | time of day]
