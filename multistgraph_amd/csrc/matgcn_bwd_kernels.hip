@@ -1097,10 +1097,8 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
   }
   __syncthreads();
   // ---- contraction: column tiles ct = w, w + 8, .. of the 4 S tiles (slot ct >> 2, hidden columns 16 (ct & 3) ..) ----
-  auto tile = [&](int ct) {
-    const int slot = ct >> 2, i0 = (ct & 3) * 16;
+  auto contract = [&](int ct, f32x4 (&acc)[4]) {
     const int nextCt = min(ct + 8, nCt - 1);
-    f32x4 acc[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1122,17 +1120,62 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
       for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wg.w, acc[rt]);
       __builtin_amdgcn_sched_barrier(0);        // keeps the A reads of later groups from being hoisted (they spilled)
     }
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int b = rowBase + rt * 16 + 4 * kq + e;
-        if (b >= p.rows) continue;
-        float* dst = p.dA + (((size_t)b * p.S + slot) * p.Np + n) * 64 + i0 + j;
-        *dst = p.beta != 0.f ? *dst + acc[rt][e] : acc[rt][e];
-      }
   };
-  for (int ct = w; ct < nCt; ct += 8) tile(ct);
+  if constexpr (O <= 128) {
+    // Round 3: the eight tiles of a pass are two whole slots of the node's 64 rows - [2][64 rows][64 columns] - and leave
+    // through LDS as 256-byte rows (float4 per thread, read-modify-write where the block already holds the x-column
+    // gradient of the layer above) instead of as 32 scalar stores / read-modify-writes per lane in 64-byte pieces: the
+    // next kernel of the chain (the transposed mix) reads exactly these rows.
+    __shared__ __attribute__((aligned(16))) float Out[2 * 4096];
+    const int passes = (nCt + 7) >> 3;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int ct = w + 8 * pass;
+      if (ct < nCt) {                             // wave-uniform
+        f32x4 acc[4];
+        contract(ct, acc);
+        float* tileOut = Out + (w >> 2) * 4096;
+        const int i0 = (w & 3) * 16;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int lb = rt * 16 + 4 * kq + e, col = i0 + j;
+            tileOut[(lb * 16 + ((col >> 2) ^ (lb & 15))) * 4 + (col & 3)] = acc[rt][e];
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 512 * q, sl = idx >> 10, lb = (idx >> 4) & 63, s4 = idx & 15;
+        const int slot = 2 * pass + sl, b = rowBase + lb;
+        if (slot < p.S && b < p.rows) {
+          float4 v = *reinterpret_cast<const float4*>(&Out[sl * 4096 + (lb * 16 + (s4 ^ (lb & 15))) * 4]);
+          float* dst = p.dA + (((size_t)b * p.S + slot) * p.Np + n) * 64 + 4 * s4;
+          if (p.beta != 0.f) {
+            const float4 o = *reinterpret_cast<const float4*>(dst);
+            v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+          }
+          *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+      if (pass + 1 < passes) __syncthreads();
+    }
+  } else {
+    for (int ct = w; ct < nCt; ct += 8) {
+      f32x4 acc[4];
+      contract(ct, acc);
+      const int slot = ct >> 2, i0 = (ct & 3) * 16;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int b = rowBase + rt * 16 + 4 * kq + e;
+          if (b >= p.rows) continue;
+          float* dst = p.dA + (((size_t)b * p.S + slot) * p.Np + n) * 64 + i0 + j;
+          *dst = p.beta != 0.f ? *dst + acc[rt][e] : acc[rt][e];
+        }
+    }
+  }
 }
 
 // ---- node-adaptive weight gradients of 64-channel rows: every slot of a node in ONE workgroup ----------------------
