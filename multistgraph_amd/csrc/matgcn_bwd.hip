@@ -459,7 +459,7 @@ int bwd_head(Pass& pass, const float* dOut) {
     if (b.dropMask) {   // the dropout mask (B, hT, N, H) of the steps the head saw, applied where the gradient is produced
       q.scaleC = b.dropMask; q.bS1 = (long)N * H; q.bS2 = (long)hT * N * H; q.sSm = H; q.sSn = 1;
     }
-    RETURN_IF(gemm(q, hT, s, BG_HEAD));
+    RETURN_IF(gemm(q, hT, s, BG_HEAD));   // (a row-per-16-lanes VALU kernel for this K = CH product was measured: 205 vs 154 us)
     // the head's weight gradient feeds nothing in this pass: with two streams it runs on the second one (behind the
     // operand preparation, joined with the last layer's weight gradients) instead of in front of the first chain
     hipStream_t hs = s;
@@ -1284,10 +1284,16 @@ static int forward_train_impl(const matgcn_dims* dims, const matgcn_params* para
   float* x0p = c.ws + P.oX0p;
   if (src) RETURN_IF(fuse_padded(c, src->series, x0p, src->label_start, src->rel_steps, src->series_steps));
   else RETURN_IF(fuse_padded(c, X, x0p));
+  // graph layers: the top layer's update kernel writes the dropped-out sequence beside the plain one (a pass of its own
+  // over 3 x 163 MB used to sit between the encoder and the head, 0.14 ms that nothing hides)
+  const bool fusedDrop = drop_mask != nullptr && !P.gcnOff;
+  if (fusedDrop) c.dropMask = drop_mask;
   RETURN_IF(encoder_padded(c, x0p, h0, nullptr));
   if (side) HIP_OK(hipStreamWaitEvent(c.s, g_wf.auxDone, 0));
   const float* seqTop = c.ws + P.oSeq[P.L - 1];
-  if (drop_mask) {   // mask (B, headT, N, H) on the steps the head convolves (fnn_off: the last one)
+  if (fusedDrop) {
+    seqTop = c.train + c.R.oSeqDrop;
+  } else if (drop_mask) {   // mask (B, headT, N, H) on the steps the head convolves (fnn_off: the last one)
     const size_t ofs = (size_t)(P.T - P.headT) * P.B * P.Np * H;
     float* dropped = c.train + c.R.oSeqDrop;
     hipLaunchKernelGGL(k_apply_mask, dim3(blocks_for((size_t)P.headT * P.B * P.Np * H)), dim3(256), 0, c.s, seqTop + ofs,

@@ -537,6 +537,8 @@ struct Ctx {
   hipStream_t s;
   float* train = nullptr;     // matgcn_forward_train: the training buffer (activations are saved into it)
   TrainPlan R;
+  const float* dropMask = nullptr;   // matgcn_forward_train: (B, headT, N, H) dropout mask of the head's input, applied by the
+                                     // top layer's update kernel as it writes the sequence (graph layers)
   size_t h0LayerStride = 0;   // floats between the layers of the caller's h0 (0: B*N*H; the batch-split halves see the
                               // caller's full-batch layout)
 };
@@ -697,7 +699,14 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
     if (rows32) hipLaunchKernelGGL((k_update16<1, false, 32>), grid, dim3(512), UPDATE_LDS / 2, s, a);
     else if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
-    else if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
+    else if (save) {
+      if (c.dropMask && l == P.L - 1 && t >= P.T - P.headT && a.seq) {   // the head's dropout rides in the sequence store
+        a.dropMask = c.dropMask + (size_t)(t - (P.T - P.headT)) * P.N * H;
+        a.dropRowStride = (long)P.headT * P.N * H;
+        a.seqDrop = c.train + c.R.oSeqDrop + (a.seq - (c.ws + P.oSeq[l]));
+      }
+      hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
+    }
     else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
     hipLaunchKernelGGL((k_update16<0, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);

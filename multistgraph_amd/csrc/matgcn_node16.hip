@@ -85,6 +85,11 @@ struct Node16Args {
   long seqRowStride;
   // training (SAVE instantiations): activations of this step kept for the backward, each [rows][Np][64]
   float *svZ, *svR, *svHC, *svZ2, *svR2, *svHC2;
+  // training, top layer: the dropout in front of the head (MultiATGCN.py:416) applied where the sequence is written -
+  // seqDrop[b*seqRowStride + n*64 + o] = seq value * dropMask[b*dropRowStride + n*64 + o]   (null: no dropout here)
+  const float* dropMask;
+  long dropRowStride;
+  float* seqDrop;
 };
 
 __device__ __forceinline__ float sigmoid16(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -755,6 +760,13 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (sq ^ (lb & 15))) * 4]);
     store_wt16(a.hout, ((size_t)b * a.Np + n) * 64 + sq * 4, v);
     if (a.seq) store_wt16(a.seq, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4, v);
+    if constexpr (SAVE) {
+      if (a.seqDrop) {
+        const float4 m = *reinterpret_cast<const float4*>(a.dropMask + (size_t)b * a.dropRowStride + (size_t)n * 64 + sq * 4);
+        *reinterpret_cast<float4*>(a.seqDrop + (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4) =
+            make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+      }
+    }
   }
 }
 
