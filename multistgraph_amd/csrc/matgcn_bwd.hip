@@ -282,6 +282,13 @@ int adaptive_grad(const Bwd& b, const float* dA, const float* U, int rows, int C
       continue;
     }
 #endif
+    if (nodeMajor && Cc == 2 && rows % 8 == 0) {   // layer 0's two-channel x part: dedicated small kernel
+      const unsigned t32 = (unsigned)((P.N + 31) / 32);
+      hipLaunchKernelGGL(k_adj_grad_narrow2, dim3(t32, t32, 2), dim3(256), 0, b.c.s, dA + slot, U, rows, P.N, P.Np, 2,
+                         dT + (size_t)j * P.N * P.N);
+      CHECK_LAUNCH();
+      continue;
+    }
     GemmArgs g = gemm_args(dA + slot, U, dT + (size_t)j * P.N * P.N, P.N, P.N, Cc);
     g.K2 = rows;
     g.sAm = Cc; g.sAk = 1; g.sAk2 = (long)S * P.Np * Cc;
@@ -1213,6 +1220,7 @@ int backward_impl(Bwd& b, const float* dOut) {
       RETURN_IF(bwd_chain(q, L));
       if (q.twoStreams) HIP_OK(hipEventRecord(g_wf.step[0][l], q.s));    // the weight-gradient stream forks here
       RETURN_IF(bwd_x_columns(q, L));
+      if (l == 0) RETURN_IF(bwd_fuse_heads(q));   // dX0 is complete on this stream: the head-fusion gradients need nothing else
       if (q.twoStreams) {   // DAx is complete (layers above the first: with the top chunk, on the x-column stream)
         if (l > 0) HIP_OK(hipStreamWaitEvent(q.s, g_wf.bxcol[l][(P.T - 1) / q.chunk * q.chunk], 0));
         HIP_OK(hipEventRecord(g_wf.mixed[0][l], q.s));
@@ -1228,7 +1236,7 @@ int backward_impl(Bwd& b, const float* dOut) {
   }
   if (q.twoStreams)
     for (int l = 0; l < P.L; ++l) HIP_OK(hipStreamWaitEvent(q.s, g_wf.step[1][l], 0));   // join
-  RETURN_IF(bwd_fuse_heads(q));
+  if (P.gcnOff) RETURN_IF(bwd_fuse_heads(q));   // (graph layers: done right behind layer 0's x columns, see above)
   return bwd_adaptive_adjacency(q);
 }
 

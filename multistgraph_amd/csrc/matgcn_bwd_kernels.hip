@@ -1440,6 +1440,51 @@ __global__ __launch_bounds__(256) void k_adj_grad(AdjGradArgs g) {
       }
 }
 
+// the same gradient for layer 0's NARROW x part with two input channels: dT[n][m] += sum_{r,c} dA[n][r][c] * x[r][m][c],
+// dA node-major (a node's rows*2 values contiguous: the A operand's float4 is four reduction steps), x time-major
+// [r][Np][2] (the four steps of a lane are the two channels of two consecutive rows: two float2).  1 GFLOP: the generic
+// GEMM (K = 2 per batch item, 1 536 batch items) took 154 us for it; 32 x 32 output tiles per wave, K cut over waves and
+// workgroups, fp32 atomics.
+__global__ __launch_bounds__(256) void k_adj_grad_narrow2(const float* __restrict__ dA, const float* __restrict__ x,
+                                                          int rows, int N, int Np, int splits, float* __restrict__ dT) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.y * 32, m0 = blockIdx.x * 32;
+  const int K = rows * 2, groups = K >> 4, parts = splits * 4, part = blockIdx.z * 4 + w;
+  const int per = (groups + parts - 1) / parts, g0 = part * per, g1 = min(g0 + per, groups);
+  const float* a0 = dA + (size_t)min(n0 + j, N - 1) * K + 4 * kq;
+  const float* a1 = dA + (size_t)min(n0 + 16 + j, N - 1) * K + 4 * kq;
+  const size_t bm0 = (size_t)min(m0 + j, N - 1) * 2, bm1 = (size_t)min(m0 + 16 + j, N - 1) * 2;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int g = g0; g < g1; ++g) {
+    const float4 av0 = *reinterpret_cast<const float4*>(a0 + 16 * g), av1 = *reinterpret_cast<const float4*>(a1 + 16 * g);
+    const size_t r = (size_t)(8 * g + 2 * kq) * Np * 2;
+    const float2 b00 = *reinterpret_cast<const float2*>(x + r + bm0), b01 = *reinterpret_cast<const float2*>(x + r + (size_t)Np * 2 + bm0);
+    const float2 b10 = *reinterpret_cast<const float2*>(x + r + bm1), b11 = *reinterpret_cast<const float2*>(x + r + (size_t)Np * 2 + bm1);
+    acc[0][0] = MFMA16(av0.x, b00.x, acc[0][0]); acc[0][1] = MFMA16(av0.x, b10.x, acc[0][1]);
+    acc[1][0] = MFMA16(av1.x, b00.x, acc[1][0]); acc[1][1] = MFMA16(av1.x, b10.x, acc[1][1]);
+    acc[0][0] = MFMA16(av0.y, b00.y, acc[0][0]); acc[0][1] = MFMA16(av0.y, b10.y, acc[0][1]);
+    acc[1][0] = MFMA16(av1.y, b00.y, acc[1][0]); acc[1][1] = MFMA16(av1.y, b10.y, acc[1][1]);
+    acc[0][0] = MFMA16(av0.z, b01.x, acc[0][0]); acc[0][1] = MFMA16(av0.z, b11.x, acc[0][1]);
+    acc[1][0] = MFMA16(av1.z, b01.x, acc[1][0]); acc[1][1] = MFMA16(av1.z, b11.x, acc[1][1]);
+    acc[0][0] = MFMA16(av0.w, b01.y, acc[0][0]); acc[0][1] = MFMA16(av0.w, b11.y, acc[0][1]);
+    acc[1][0] = MFMA16(av1.w, b01.y, acc[1][0]); acc[1][1] = MFMA16(av1.w, b11.y, acc[1][1]);
+  }
+  if (g0 >= g1) return;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 16 * p + 4 * kq + e, m = m0 + 16 * q + j;
+        if (n < N && m < N) unsafeAtomicAdd(dT + (size_t)n * N + m, acc[p][q][e]);
+      }
+}
+
 // ---- node-adaptive weight gradients of layer 0's NARROW x rows (C0 = 2..16 input channels) ------------------------
 //   dWpG[n][s][c][o] += sum_rows XA[rows][n][s][c] * dpg[rows][n][o]      (o < 128; dWpU with dpu alike)
 // XA slot 0 = the input rows themselves (time-major x0), slots 1.. = the fold's plain matrix MX0 [(k, n)][ld] with
