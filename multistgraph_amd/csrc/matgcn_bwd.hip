@@ -701,13 +701,19 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
 #define XN_LAUNCH(C0_, S_)                                                                                               \
   hipLaunchKernelGGL((k_xcol_narrow<C0_, S_>), dim3((unsigned)((rowsTB + 255) / 256), (unsigned)N), dim3(256), 0, s, DPG, \
                      DPU, WpG, WpU, DAx, rowsTB, N, Np, I)
-    if (C == 2 && S == 4) XN_LAUNCH(2, 4);
-    else if (C == 2 && S == 5) XN_LAUNCH(2, 5);
-    else if (C == 2 && S == 2) XN_LAUNCH(2, 2);
-    else if (C == 2 && S == 1) XN_LAUNCH(2, 1);
+    const int xnTpw = 6;   // 16-row tiles per wave of the matrix-core kernel
+#define XNM_LAUNCH(C0_, S_)                                                                                              \
+  hipLaunchKernelGGL((k_xcol_narrow_mfma<C0_, S_>),                                                                      \
+                     dim3((unsigned)(((rowsTB + 15) / 16 + 4 * xnTpw - 1) / (4 * xnTpw)), (unsigned)N), dim3(256), 0, s,  \
+                     DPG, DPU, WpG, WpU, DAx, rowsTB, N, Np, I, xnTpw)
+    if (C == 2 && S == 4) XNM_LAUNCH(2, 4);
+    else if (C == 2 && S == 5) XNM_LAUNCH(2, 5);
+    else if (C == 2 && S == 2) XNM_LAUNCH(2, 2);
+    else if (C == 2 && S == 1) XNM_LAUNCH(2, 1);
     else if (C == 9 && S == 4) XN_LAUNCH(9, 4);
     else narrowDone = false;
 #undef XN_LAUNCH
+#undef XNM_LAUNCH
     if (narrowDone) {
       CHECK_LAUNCH();
     } else {

@@ -1776,6 +1776,63 @@ __global__ __launch_bounds__(256) void k_res_wgrad_narrow(const float* __restric
   }
 }
 
+// The same x-column gradients on the matrix cores (round 3; S * C0 <= 16): per node a [rows x 192] . [192 x S*C0] product.
+// Both operands lie K-contiguous (a gradient row's 192 columns; a weight row's 192 columns), so a lane's float4 is four
+// reduction steps on either side; the (slot, channel) pairs are the 16 columns of ONE MFMA tile, the node's 12 weight
+// fragments stay in registers, and a wave walks 16-row tiles with the next tile's 12 row pieces in flight.  The VALU
+// kernel above reads the same rows 16 bytes per lane and instruction (189 us).
+template <int C0, int S>
+__global__ __launch_bounds__(256) void k_xcol_narrow_mfma(const float* __restrict__ dpg, const float* __restrict__ dpu,
+                                                          const float* __restrict__ WpG, const float* __restrict__ WpU,
+                                                          float* __restrict__ dA, int rows, int N, int Np, int I,
+                                                          int tilesPerWave) {
+  static_assert(S * C0 <= 16, "one MFMA column tile");
+  const int n = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+  const int nTiles = (rows + 15) >> 4;
+  const int tile0 = (blockIdx.x * 4 + w) * tilesPerWave, tile1 = min(tile0 + tilesPerWave, nTiles);
+  if (tile0 >= tile1) return;
+  // B fragments: column j = (slot, channel), groups 0..7 the gate AGCN's 128 columns, 8..11 the update AGCN's 64
+  const int sl = min(j / C0, S - 1), ch = j - (j / C0) * C0;
+  const bool colLive = j < S * C0;
+  const size_t wrow = ((size_t)n * S + sl) * I + ch;
+  float4 bf[12];
+#pragma unroll
+  for (int g = 0; g < 12; ++g) {
+    const float4 v = g < 8 ? *reinterpret_cast<const float4*>(WpG + wrow * 128 + 16 * g + 4 * kq)
+                           : *reinterpret_cast<const float4*>(WpU + wrow * 64 + 16 * (g - 8) + 4 * kq);
+    bf[g] = colLive ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto load = [&](int tile, float4 (&a)[12]) {
+    const size_t rowN = (size_t)min(tile * 16 + j, rows - 1) * Np + n;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const float4*>(dpg + rowN * 128 + 16 * g + 4 * kq);
+#pragma unroll
+    for (int g = 8; g < 12; ++g) a[g] = *reinterpret_cast<const float4*>(dpu + rowN * 64 + 16 * (g - 8) + 4 * kq);
+  };
+  float4 cur[12], nxt[12];
+  load(tile0, cur);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    load(min(tile + 1, tile1 - 1), nxt);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      acc = MFMA16(cur[g].x, bf[g].x, acc);
+      acc = MFMA16(cur[g].y, bf[g].y, acc);
+      acc = MFMA16(cur[g].z, bf[g].z, acc);
+      acc = MFMA16(cur[g].w, bf[g].w, acc);
+    }
+    if (colLive) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = tile * 16 + 4 * kq + e;
+        if (row < rows) dA[(((size_t)sl * Np + n) * rows + row) * C0 + ch] = acc[e];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 12; ++g) cur[g] = nxt[g];
+  }
+}
+
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
