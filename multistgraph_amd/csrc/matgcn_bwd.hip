@@ -687,6 +687,12 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
   return MATGCN_OK;
 }
 
+inline bool prep_hoisted(const Pass& pass, int l) { return pass.twoStreams && l >= pass.b.c.P.L - 2; }
+// layer 0 with two input channels: bwd_x_columns takes the x-column blocks of the residual nn.Linear weight gradients
+// along (k_res_narrow2).  It reads the time-major input, which exists that early only when the operands were prepared at
+// the start of the backward (event auxDone on the second stream).
+inline bool res_narrow_fused(const Pass& pass, const LayerBufs& L) { return L.narrow && L.C == 2 && prep_hoisted(pass, L.l); }
+
 // x columns of both AGCNs and of the residual cell -> gradient of the layer's input sequence
 int bwd_x_columns(Pass& pass, const LayerBufs& L) {
   PASS_LOCALS(pass);
@@ -751,7 +757,21 @@ int bwd_x_columns(Pass& pass, const LayerBufs& L) {
     CHECK_LAUNCH();
   }
   const long rrows = (long)rowsTB * Np;
-  if (narrow && (C == 2 || C == 9)) {   // residual cell x columns of a narrow input: one pass over the 192 gradients per row
+  if (res_narrow_fused(pass, L)) {
+    HIP_OK(hipStreamWaitEvent(s, g_wf.auxDone, 0));     // the hoisted operand preparation (X0tm) is done
+    // two input channels: the x columns AND the x-column blocks of the residual nn.Linear weight gradients in one pass over
+    // the residual cell's gradients (bwd_layer_other_grads, later on this stream, finds its weight tensors cleared and those
+    // blocks done: res_narrow_fused)
+    const matgcn_linear_grads& gg = g->res_gate[l];
+    const matgcn_linear_grads& gu = g->res_update[l];
+    if (!gg.weight || !gu.weight) return MATGCN_ERR_NULL;
+    RETURN_IF(zero_async(gg.weight, 128L * I, s));
+    RETURN_IF(zero_async(gu.weight, 64L * I, s));
+    const float* Xall = tr + R.oX0tm;
+    const dim3 grid((unsigned)((rrows + 15) / 16 < 2048 ? (rrows + 15) / 16 : 2048));
+    hipLaunchKernelGGL(k_res_narrow2, grid, dim3(256), 0, s, DPU2, DPG2, RU, RG, Xall, I, dXall, gu.weight, gg.weight, rrows);
+    CHECK_LAUNCH();
+  } else if (narrow && (C == 2 || C == 9)) {   // residual cell x columns of a narrow input: one pass over the 192 gradients per row
     const dim3 grid((unsigned)((rrows + 15) / 16 < 4096 ? (rrows + 15) / 16 : 4096));
     if (C == 2) hipLaunchKernelGGL(k_res_xcol_narrow<2>, grid, dim3(256), 0, s, DPU2, DPG2, RU, RG, I, dXall, rrows);
     else hipLaunchKernelGGL(k_res_xcol_narrow<9>, grid, dim3(256), 0, s, DPU2, DPG2, RU, RG, I, dXall, rrows);
@@ -788,13 +808,18 @@ int bwd_layer_other_grads(Pass& pass, const LayerBufs& L, const Bwd& bx, const f
   const matgcn_linear_grads& gg = g->res_gate[l];
   const matgcn_linear_grads& gu = g->res_update[l];
   if (!gg.weight || !gg.bias || !gu.weight || !gu.bias) return MATGCN_ERR_NULL;
-  RETURN_IF(zero_async(gg.weight, 128L * I, xs));
-  RETURN_IF(zero_async(gu.weight, 64L * I, xs));
+  const bool resNarrowFused = res_narrow_fused(pass, L);   // bwd_x_columns cleared the tensors and took the x-column blocks along
+  if (!resNarrowFused) {
+    RETURN_IF(zero_async(gg.weight, 128L * I, xs));
+    RETURN_IF(zero_async(gu.weight, 64L * I, xs));
+  }
   const long rows = (long)rowsTB * Np;
   RETURN_IF(zero_async(gg.bias, 128, xs));
   RETURN_IF(zero_async(gu.bias, 64, xs));
   bool biasG = false, biasU = false;   // the h-column GEMMs (64 input channels: fast kernel) take the bias sums along
-  if (narrow && (C == 2 || C == 9)) {   // both x-column blocks in one pass over the residual cell's gradients
+  if (resNarrowFused) {
+    // (done by k_res_narrow2 in bwd_x_columns)
+  } else if (narrow && (C == 2 || C == 9)) {   // both x-column blocks in one pass over the residual cell's gradients
     const dim3 grid((unsigned)((rows + 15) / 16 < 1024 ? (rows + 15) / 16 : 1024));
     if (C == 2) hipLaunchKernelGGL(k_res_wgrad_narrow<2>, grid, dim3(256), 0, xs, DPU2, DPG2, Xall, I, gu.weight, gg.weight, rows);
     else hipLaunchKernelGGL(k_res_wgrad_narrow<9>, grid, dim3(256), 0, xs, DPU2, DPG2, Xall, I, gu.weight, gg.weight, rows);
@@ -842,7 +867,6 @@ int bwd_prep_operands(Pass& pass, const LayerBufs& L, hipStream_t on) {
   CHECK_LAUNCH();
   return MATGCN_OK;
 }
-inline bool prep_hoisted(const Pass& pass, int l) { return pass.twoStreams && l >= pass.b.c.P.L - 2; }
 
 // Weight gradients of a graph layer, on the second stream when there is one (forked by the caller right after the
 // layer's chain: event step[0][l]; the x columns of the layer run on the main stream meanwhile and signal mixed[0][l]).
@@ -1202,6 +1226,7 @@ int backward_impl(Bwd& b, const float* dOut) {
     HIP_OK(hipStreamWaitEvent(q.ws, g_wf.fork, 0));
     for (int l = P.L - 1; l >= 0; --l)
       if (prep_hoisted(q, l)) RETURN_IF(bwd_prep_operands(q, LB[l], q.ws));
+    HIP_OK(hipEventRecord(g_wf.auxDone, q.ws));   // (k_res_narrow2 on the chain's stream reads the time-major input)
   }
   RETURN_IF(bwd_clear(q));
   RETURN_IF(bwd_head(q, dOut));

@@ -1833,6 +1833,74 @@ __global__ __launch_bounds__(256) void k_xcol_narrow_mfma(const float* __restric
   }
 }
 
+// k_res_xcol_narrow and k_res_wgrad_narrow in ONE pass over the residual cell's gradients (two input channels: the 24
+// weights and the 24 accumulators of a lane fit the registers): dX += [dpu2 | dpg2] . [RU | RG][:, 0:2] and
+// dRU / dRG[:, 0:2] += [dpu2 | dpg2]^T . x.  The caller has cleared dRU / dRG (whole tensors) on this stream.
+__global__ __launch_bounds__(256) void k_res_narrow2(const float* __restrict__ dpu2, const float* __restrict__ dpg2,
+                                                     const float* __restrict__ RU, const float* __restrict__ RG,
+                                                     const float* __restrict__ x, int I, float* __restrict__ dX,
+                                                     float* __restrict__ dRU, float* __restrict__ dRG, long rows) {
+  __shared__ float part[4][192 * 2];
+  const int lane = threadIdx.x & 63, sub = lane & 15, rw = lane >> 4, w = threadIdx.x >> 6;
+  float wt[12][2], acc[12][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      wt[e][c] = RU[(size_t)(4 * sub + e) * I + c];
+      wt[4 + e][c] = RG[(size_t)(4 * sub + e) * I + c];
+      wt[8 + e][c] = RG[(size_t)(64 + 4 * sub + e) * I + c];
+    }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; }
+  const long wave = (long)blockIdx.x * 4 + w, waves = (long)gridDim.x * 4;
+  for (long r0 = wave * 4; r0 < rows; r0 += waves * 4) {
+    const long row = min(r0 + rw, rows - 1);
+    const bool liveRow = r0 + rw < rows;
+    const float4 u = *reinterpret_cast<const float4*>(dpu2 + row * 64 + 4 * sub);
+    const float4 ga = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 4 * sub);
+    const float4 gb = *reinterpret_cast<const float4*>(dpg2 + row * 128 + 64 + 4 * sub);
+    const float2 xv = *reinterpret_cast<const float2*>(x + row * 2);
+    const float d[12] = {u.x, u.y, u.z, u.w, ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    float s0 = 0.f, s1 = 0.f;
+    const float x0 = liveRow ? xv.x : 0.f, x1 = liveRow ? xv.y : 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      s0 = fmaf(d[i], wt[i][0], s0); s1 = fmaf(d[i], wt[i][1], s1);
+      acc[i][0] = fmaf(d[i], x0, acc[i][0]); acc[i][1] = fmaf(d[i], x1, acc[i][1]);
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m, 16); s1 += __shfl_xor(s1, m, 16); }
+    if (sub == 0 && liveRow) {
+      float2* dst = reinterpret_cast<float2*>(dX + (r0 + rw) * 2);
+      const float2 o = *dst;
+      *dst = make_float2(o.x + s0, o.y + s1);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float v = acc[i][c];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      acc[i][c] = v;
+    }
+  if (rw == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int o = i < 4 ? 4 * sub + i : (i < 8 ? 64 + 4 * sub + (i - 4) : 128 + 4 * sub + (i - 8));
+      part[w][o * 2] = acc[i][0]; part[w][o * 2 + 1] = acc[i][1];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 192 * 2; e += 256) {
+    const float v = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+    const int o = e >> 1, c = e & 1;
+    if (o < 64) unsafeAtomicAdd(dRU + (size_t)o * I + c, v);
+    else unsafeAtomicAdd(dRG + (size_t)(o - 64) * I + c, v);
+  }
+}
+
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
