@@ -879,14 +879,43 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   const float* Xall = l == 0 ? tr + R.oX0tm : c.ws + P.oSeq[l - 1];
   float* Hprev = tr + R.oHprev[par]; float* ZH = tr + R.oZH[par];
   if (!prep_hoisted(pass, l)) RETURN_IF(bwd_prep_operands(pass, L, ws));
-  if (twoStreams && tailOnMain) {   // the main stream takes the other gradients once these operands exist
-    HIP_OK(hipEventRecord(g_wf.xdone[0][l], ws));
-    HIP_OK(hipStreamWaitEvent(s, g_wf.xdone[0][l], 0));
-    RETURN_IF(bwd_layer_other_grads(pass, L, b, Xall));
-  }
   // node-adaptive weight gradients (plain folded layout) and biases; the graph-mixed rows are the forward's
   float* dWpG = tr + R.oDWp[l][0];
   float* dWpU = tr + R.oDWp[l][1];
+  // x rows of layer 0 with a dedicated narrow kernel (see below): returns false when the shape has none
+  const long ldx = rup((long)rowsTB * P.C0, 64);
+  auto narrow_wgrad = [&](hipStream_t on) -> bool {
+#define WN_LAUNCH(C0_, S_)                                                                                               \
+  hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N, WN_PARTS), dim3(192 * WN_GROUPS), 0, on, Xall,          \
+                     c.ws + P.oMX0, ldx, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
+#define WNM_LAUNCH(C0_, S_)                                                                                              \
+  hipLaunchKernelGGL((k_wgrad_narrow_mfma<C0_, S_>), dim3((unsigned)N, WNM_PARTS), dim3(256), 0, on, Xall, c.ws + P.oMX0,  \
+                     ldx, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
+    if (P.C0 == 2 && S == 4) WNM_LAUNCH(2, 4);
+    else if (P.C0 == 2 && S == 5) WNM_LAUNCH(2, 5);
+    else if (P.C0 == 2 && S == 2) WNM_LAUNCH(2, 2);
+    else if (P.C0 == 2 && S == 1) WNM_LAUNCH(2, 1);
+    else if (P.C0 == 9 && S == 4) WN_LAUNCH(9, 4);
+    else return false;
+#undef WN_LAUNCH
+#undef WNM_LAUNCH
+    return true;
+  };
+  const bool narrowShape = l == 0 && ((P.C0 == 2 && (S == 4 || S == 5 || S == 2 || S == 1)) || (P.C0 == 9 && S == 4));
+  bool narrowOnMain = false;
+  if (twoStreams && tailOnMain) {   // the main stream takes the other gradients once these operands exist
+    HIP_OK(hipEventRecord(g_wf.xdone[0][l], ws));
+    HIP_OK(hipStreamWaitEvent(s, g_wf.xdone[0][l], 0));
+    // (behind that event the accumulators are cleared too.)  The narrow x-row gradients go FIRST on the main stream: the
+    // weight-gradient stream is the longer of the two in the tail, and its pools need them last
+    if (narrowShape) {
+      narrow_wgrad(s);
+      CHECK_LAUNCH();
+      HIP_OK(hipEventRecord(g_wf.bfork, s));      // (bfork: recorded once at the start of the pass, free again by now)
+      narrowOnMain = true;
+    }
+    RETURN_IF(bwd_layer_other_grads(pass, L, b, Xall));
+  }
   const long gStep = (long)N * B * P.Ks * H;
   int rc = MATGCN_OK;
   // recurrent rows h_{t-1} and their mixes
@@ -935,28 +964,14 @@ int bwd_layer_weights(Pass& pass, const LayerBufs& L, bool tailOnMain) {
   }
   RETURN_IF(rc);
   if (l == 0) {  // x rows of layer 0: the plain matrix of the fold, [(s, n)][ld] with column (b*T + t)*C0 + c
-    const long ld = rup((long)rowsTB * P.C0, 64);
     // narrow x rows: M = C0 is no GEMM shape; the common widths (flow + time of day, + day of week) and stack sizes
     // (multi-graph: identity + 3 or 4 dense slots, single graph: + 1) have a dedicated kernel (k_wgrad_narrow)
-    bool narrowDone = true;
-#define WN_LAUNCH(C0_, S_)                                                                                               \
-  hipLaunchKernelGGL((k_wgrad_narrow<C0_, S_>), dim3((unsigned)N, WN_PARTS), dim3(192 * WN_GROUPS), 0, ws, Xall,          \
-                     c.ws + P.oMX0, ld, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
-#define WNM_LAUNCH(C0_, S_)                                                                                              \
-  hipLaunchKernelGGL((k_wgrad_narrow_mfma<C0_, S_>), dim3((unsigned)N, WNM_PARTS), dim3(256), 0, ws, Xall, c.ws + P.oMX0,  \
-                     ld, DPG, DPU, dWpG, dWpU, T, B, N, Np, I)
-    if (P.C0 == 2 && S == 4) WNM_LAUNCH(2, 4);
-    else if (P.C0 == 2 && S == 5) WNM_LAUNCH(2, 5);
-    else if (P.C0 == 2 && S == 2) WNM_LAUNCH(2, 2);
-    else if (P.C0 == 2 && S == 1) WNM_LAUNCH(2, 1);
-    else if (P.C0 == 9 && S == 4) WN_LAUNCH(9, 4);
-    else narrowDone = false;
-#undef WN_LAUNCH
-#undef WNM_LAUNCH
-    if (narrowDone) {
+    if (narrowOnMain) {
+      HIP_OK(hipStreamWaitEvent(ws, g_wf.bfork, 0));   // launched on the main stream above: the pools below read them
+    } else if (narrow_wgrad(ws)) {
       CHECK_LAUNCH();
     } else {
-      MixedRows mx = {c.ws + P.oMX0, ld, (long)Np * ld, P.C0, (long)T * P.C0, T, B};
+      MixedRows mx = {c.ws + P.oMX0, ldx, (long)Np * ldx, P.C0, (long)T * P.C0, T, B};
       RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPG, 128, I, 0, 0, rowsTB, dWpG));
       RETURN_IF(node_weight_grad(bw, Xall, mx, C, DPU, 64, I, 0, 0, rowsTB, dWpU));
     }
