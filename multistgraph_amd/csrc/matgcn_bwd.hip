@@ -605,7 +605,12 @@ int bwd_x_chunk(Pass& pass, const LayerBufs& L, int t0, int t1) {
                        (size_t)B, Np, C, S);
     CHECK_LAUNCH();
   }
-  {  // residual cell x columns
+  if (C == H) {   // residual cell x columns: one pass over both gradient blocks of the chunk (k_res_xcol64)
+    const long rr = (long)rows * Np, tiles = (rr + 31) / 32;
+    hipLaunchKernelGGL(k_res_xcol64, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, xs, DPU2 + r0 * Np * H,
+                       DPG2 + r0 * Np * 128, RU, RG, I, dXall + r0 * Np * C, rr);
+    CHECK_LAUNCH();
+  } else {  // residual cell x columns
     GemmArgs q = gemm_args(DPU2 + r0 * Np * H, RU, dXall + r0 * Np * C, rows * Np, C, H);
     q.sAm = H; q.sAk = 1; q.sBk = I; q.sBn = 1; q.sCm = C; q.sCn = 1; q.beta = 1.f;
     RETURN_IF(gemm(q, 1, xs));

@@ -1901,6 +1901,78 @@ __global__ __launch_bounds__(256) void k_res_narrow2(const float* __restrict__ d
   }
 }
 
+// ---- x columns of the residual cell for a 64-channel input (the layers above the first) ---------------------------
+//   dX[row][0:64] += dpu2[row][0:64] . RU[:, 0:64] + dpg2[row][0:128] . RG[:, 0:64]          (RU (64, I), RG (128, I))
+// Two launches of the generic GEMM per x-column chunk (K-contiguous A operands: its scalar staging path, 46 us each, ten
+// a step) re-read the residual cell's gradients twice and read-modify-wrote dX twice.  One pass: a 32-row tile of both
+// gradients goes to LDS as whole rows (16-byte slots XOR-swizzled by the row), wave w contracts it with its 16 output
+// columns - the 192 x 16 weight fragments stay in registers, a lane's float4 of a row is four reduction steps - and the
+// 32 x 64 result is turned through LDS into float4 read-modify-writes of dX.  The next tile's rows are in flight meanwhile.
+__global__ __launch_bounds__(256) void k_res_xcol64(const float* __restrict__ dpu2, const float* __restrict__ dpg2,
+                                                    const float* __restrict__ RU, const float* __restrict__ RG, int I,
+                                                    float* __restrict__ dX, long rows) {
+  __shared__ __attribute__((aligned(16))) float As[32 * 192];
+  __shared__ __attribute__((aligned(16))) float Out[32 * 68];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  float4 bf[12];
+#pragma unroll
+  for (int g = 0; g < 12; ++g) {
+    const float* W = g < 4 ? RU + (size_t)(16 * g + 4 * kq) * I : RG + (size_t)(16 * (g - 4) + 4 * kq) * I;
+    bf[g] = make_float4(W[16 * w + j], W[(size_t)I + 16 * w + j], W[2 * (size_t)I + 16 * w + j], W[3 * (size_t)I + 16 * w + j]);
+  }
+  const long tiles = (rows + 31) >> 5;
+  struct Six { float4 v0, v1, v2, v3, v4, v5; };
+  auto one = [&](long tile, int q) {
+    const int u = tid + 256 * q, r = u / 48, slot = u - r * 48;
+    const long row = min(tile * 32 + r, rows - 1);
+    return slot < 16 ? *reinterpret_cast<const float4*>(dpu2 + row * 64 + 4 * slot)
+                     : *reinterpret_cast<const float4*>(dpg2 + row * 128 + 4 * (slot - 16));
+  };
+  auto fetch = [&](long tile) {
+    Six s6;
+    s6.v0 = one(tile, 0); s6.v1 = one(tile, 1); s6.v2 = one(tile, 2); s6.v3 = one(tile, 3); s6.v4 = one(tile, 4); s6.v5 = one(tile, 5);
+    return s6;
+  };
+  auto put = [&](int q, const float4& v) {
+    const int u = tid + 256 * q, r = u / 48, slot = u - r * 48;
+    *reinterpret_cast<float4*>(&As[(r * 48 + ((slot & ~7) | ((slot ^ r) & 7))) * 4]) = v;
+  };
+  Six cur = fetch(min((long)blockIdx.x, tiles - 1)), nxt;
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    put(0, cur.v0); put(1, cur.v1); put(2, cur.v2); put(3, cur.v3); put(4, cur.v4); put(5, cur.v5);
+    __syncthreads();
+    nxt = fetch(min(tile + (long)gridDim.x, tiles - 1));
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const int slot = 4 * g + kq;
+      const float4 a0 = *reinterpret_cast<const float4*>(&As[(j * 48 + ((slot & ~7) | ((slot ^ j) & 7))) * 4]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&As[((16 + j) * 48 + ((slot & ~7) | ((slot ^ (16 + j)) & 7))) * 4]);
+      acc[0] = MFMA16(a0.x, bf[g].x, acc[0]); acc[1] = MFMA16(a1.x, bf[g].x, acc[1]);
+      acc[0] = MFMA16(a0.y, bf[g].y, acc[0]); acc[1] = MFMA16(a1.y, bf[g].y, acc[1]);
+      acc[0] = MFMA16(a0.z, bf[g].z, acc[0]); acc[1] = MFMA16(a1.z, bf[g].z, acc[1]);
+      acc[0] = MFMA16(a0.w, bf[g].w, acc[0]); acc[1] = MFMA16(a1.w, bf[g].w, acc[1]);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Out[(16 * p + 4 * kq + e) * 68 + 16 * w + j] = acc[p][e];
+    __syncthreads();
+    {
+      const int r = tid >> 3, c8 = (tid & 7) * 8;
+      const long row = tile * 32 + r;
+      if (row < rows) {
+        float4* dst = reinterpret_cast<float4*>(dX + row * 64 + c8);
+        const float4 o0 = *reinterpret_cast<const float4*>(&Out[r * 68 + c8]), o1 = *reinterpret_cast<const float4*>(&Out[r * 68 + c8 + 4]);
+        const float4 d0 = dst[0], d1 = dst[1];
+        dst[0] = make_float4(d0.x + o0.x, d0.y + o0.y, d0.z + o0.z, d0.w + o0.w);
+        dst[1] = make_float4(d1.x + o1.x, d1.y + o1.y, d1.z + o1.z, d1.w + o1.w);
+      }
+    }
+    cur = nxt;
+  }
+}
+
 // plain copy of the support stack for the transposed graph mix: StP[kk][m] = St[m][kk] (m < N, zero beyond), i.e. row
 // kk = k*Np + n holds S_k[n][.] - the A operand of k_mix when the reduction runs over (k, n)
 __global__ __launch_bounds__(256) void k_stack_plain(const float* __restrict__ St, int ldS, int N, int rowsKK, int ldP,
