@@ -547,6 +547,7 @@ struct Ctx {
 // cell), k_px16 the whole tile; sizes above 64 KB must be opted into once per kernel
 constexpr int GATE_LDS = 3 * NODE_ROWS * 64 * (int)sizeof(float);
 constexpr int UPDATE_LDS = 4 * NODE_ROWS * 64 * (int)sizeof(float);
+constexpr int UPDATE_SAVE_LDS = 5 * NODE_ROWS * 64 * (int)sizeof(float);   // training: + the tile saved activations pass through
 int node_kernels_ready(int ldsBytes) {
   static int readyOn[MAX_DEVICES] = {0};   // function attributes are per device
   int dev = 0;
@@ -558,9 +559,9 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true, NODE_ROWS>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<0, false, NODE_ROWS>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, NODE_ROWS>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, NODE_ROWS>), at, UPDATE_SAVE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, false, NODE_ROWS>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true, NODE_ROWS>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<2, true, NODE_ROWS>), at, UPDATE_SAVE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, NODE_ROWS, true>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, NODE_ROWS, true>), at, UPDATE_LDS));
   // 32-row work items for batches of at most 32 rows (the halves of the batch-split forward)
@@ -646,6 +647,22 @@ void fill_res_args(const Ctx& c, int l, const float* xt, long xRowStride, const 
   a->blend = blend; a->seq = seq_t; a->seqRowStride = (long)P.Np * H;
 }
 
+#ifdef NODE_LAB_STAMPS   // lab builds only (tools/labs/stamps_r04.py): where the node kernels' in-kernel stamps go
+unsigned int* g_lab_stamps = nullptr;
+size_t g_lab_stamp_words = 0;
+int g_lab_stamp_launch = 0;
+extern "C" int matgcn_lab_stamps(void* buf, size_t words) {
+  g_lab_stamps = static_cast<unsigned int*>(buf); g_lab_stamp_words = words; g_lab_stamp_launch = 0;
+  return MATGCN_OK;
+}
+extern "C" int matgcn_lab_stamp_launches(void) { return g_lab_stamp_launch; }
+static unsigned int* lab_stamp_slot(unsigned gridBlocks) {
+  const size_t per = (size_t)gridBlocks * 8 * NODE_STAMPS;
+  if (!g_lab_stamps || (size_t)(g_lab_stamp_launch + 1) * per > g_lab_stamp_words) return nullptr;
+  return g_lab_stamps + (size_t)(g_lab_stamp_launch++) * per;
+}
+#endif
+
 // phase 0: mix(h) -> G;  1: gate;  2: mix(z*h) -> G;  3: update [+ residual cell + blend when `res` is set]
 int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Args* res, hipStream_t s) {
   const Plan& P = c.P;
@@ -675,6 +692,9 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   // would be half padding
   const bool rows32 = NODE_ROWS == 64 && P.B <= 32 && !save && res != nullptr && !raw && !g_node_bf16_now;
   const dim3 grid(node_items(P.N, P.B, rows32 ? 32 : NODE_ROWS));   // (node, row block) work items, XCD-paired per node
+#ifdef NODE_LAB_STAMPS
+  a.stamps = lab_stamp_slot(grid.x);
+#endif
   if (save) {
     const size_t at = (size_t)t * P.B * P.Np * H;
     a.svZ = c.train + c.R.oZ[l] + at; a.svR = c.train + c.R.oR[l] + at; a.svHC = c.train + c.R.oHC[l] + at;
@@ -705,7 +725,7 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
         a.dropRowStride = (long)P.headT * P.N * H;
         a.seqDrop = c.train + c.R.oSeqDrop + (a.seq - (c.ws + P.oSeq[l]));
       }
-      hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
+      hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, s, a);
     }
     else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
@@ -824,7 +844,7 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
           if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
             const size_t at = (size_t)t * P.B * P.Np * H;
             a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
-            hipLaunchKernelGGL((k_update16<2, true, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
+            hipLaunchKernelGGL((k_update16<2, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, cs, a);
           } else {
             hipLaunchKernelGGL((k_update16<2, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
           }

@@ -43,6 +43,9 @@
 #ifndef NODE_MIN_WAVES_32
 #define NODE_MIN_WAVES_32 4   // the 32-row instantiations of k_gate16 / k_update16
 #endif
+#ifndef NODE_XT_LATE
+#define NODE_XT_LATE 1              // k_update16: request the residual cell's x_t rows before the last K chunk
+#endif
 #ifndef PX16_RING
 #define PX16_RING 4        // k_px16: two rings (two column tiles per wave)
 #endif
@@ -90,9 +93,72 @@ struct Node16Args {
   const float* dropMask;
   long dropRowStride;
   float* seqDrop;
+#ifdef NODE_LAB_STAMPS   // tools/labs/stamps_r04.py: per-wave phase stamps of this launch (NODE_STAMPS words per wave)
+  unsigned int* stamps;
+#endif
 };
 
-__device__ __forceinline__ float sigmoid16(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ---- lab only: in-kernel phase stamps (s_memtime at wave granularity, kept in SGPRs, written once at the end) ----
+#ifdef NODE_LAB_STAMPS
+#define NODE_STAMPS 28
+struct NodeStamps {
+  unsigned int t[NODE_STAMPS];
+  __device__ __forceinline__ void at(int i) {
+    t[i] = (unsigned int)__builtin_amdgcn_s_memtime();
+    if (i == 0) t[24] = (unsigned int)__builtin_amdgcn_s_memrealtime();
+  }
+  __device__ __forceinline__ void flush(unsigned int* out) {
+    if (!out) return;
+    t[25] = (unsigned int)__builtin_amdgcn_s_memrealtime();
+    t[26] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+    t[27] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+    if ((threadIdx.x & 63) == 0) {
+      unsigned int* o = out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NODE_STAMPS;
+#pragma unroll
+      for (int i = 0; i < NODE_STAMPS; ++i) o[i] = t[i];
+    }
+  }
+};
+#define NODE_STAMP_DECL NodeStamps nst; for (int i_ = 0; i_ < NODE_STAMPS; ++i_) nst.t[i_] = 0;
+#define NODE_STAMP(i) nst.at(i)
+#define NODE_STAMP_ARG , nst
+#define NODE_STAMP_PARAM , NodeStamps& nst
+#define NODE_STAMP_FLUSH(a) nst.flush((a).stamps)
+#else
+#define NODE_STAMP_DECL
+#define NODE_STAMP(i)
+#define NODE_STAMP_ARG
+#define NODE_STAMP_PARAM
+#define NODE_STAMP_FLUSH(a)
+#endif
+
+// Gate non-linearities of the step kernels.  The node kernels' epilogues are VALU-bound stretches in which the matrix
+// pipe idles (round 4, tools/labs/stamps_r04.py: the 16 sigmoids per lane of k_gate16 took 8 200 cycles with two
+// workgroups on a CU): the IEEE expf + division of `1 / (1 + expf(-x))` is 26 VALU instructions, tanhf 30.  These forms
+// are 4 and 15: v_exp_f32 / v_rcp_f32 (1 ulp each); tanh keeps its RELATIVE accuracy near 0 with the odd series below
+// |x| = 0.25 (next term 9e-9 relative there) and (1 - t) / (1 + t), t = exp(-2|x|), above it (<= 3 ulp).
+// NODE_PRECISE_GATES=1 restores the libm forms (A/B builds).
+#ifndef NODE_PRECISE_GATES
+#define NODE_PRECISE_GATES 0
+#endif
+__device__ __forceinline__ float sigmoid16(float x) {
+#if NODE_PRECISE_GATES
+  return 1.0f / (1.0f + expf(-x));
+#else
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+#endif
+}
+__device__ __forceinline__ float tanh16(float x) {
+#if NODE_PRECISE_GATES
+  return tanhf(x);
+#else
+  const float ax = fabsf(x), x2 = x * x;
+  const float t = __builtin_amdgcn_exp2f(-2.88539008177792681472f * ax);
+  const float big = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  const float small = ax * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * (-0.0539682540f + x2 * 0.0218694885f))));
+  return copysignf(ax < 0.25f ? small : big, x);
+#endif
+}
 
 // keep v where ok, else zeros - element-wise, so the float4 stays in registers (a ?: on the structs would
 // select between their addresses and push them to scratch)
@@ -246,7 +312,7 @@ __device__ __forceinline__ void chunk_mfma(const float* buf, int rt0, int j, int
 template <int ROWS, int NRT, bool BF, typename Late>
 __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowBase, float* Hs, float* Gb, int rt0, int j,
                                             int kq, const typename NodeOp<BF>::T* wp, size_t gStride, f32x4 (&acc)[NRT],
-                                            Late&& late) {
+                                            Late&& late NODE_STAMP_PARAM) {
   constexpr int NS = ROWS / 32, CH = ROWS * 64;      // float4 per thread and chunk; floats of one LDS chunk
   const int Ks = a.Ks, gLast = 4 * (1 + Ks) - 1;
   const ChunkStage<ROWS> cs = chunk_stage<ROWS>(a, n, rowBase);
@@ -263,34 +329,48 @@ __device__ __forceinline__ void node_k_loop(const Node16Args& a, int n, int rowB
   float4 st[2][NS];
   chunk_load<ROWS>(cs, Ks, 1, st[1]);
   chunk_load<ROWS>(cs, Ks, 2, st[0]);
+  // (round 4 lab: requesting these two chunks only after the state rows are in LDS - the waves sit 6-8 k cycles in the
+  //  vector-memory issue queue before this point - changed nothing: 6.75 vs 6.74 ms, profiles/r04_node_epilogue_lab.log)
 #pragma unroll
   for (int q = 0; q < NRT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  NODE_STAMP(1);   // requests issued
   chunk_store<ROWS, BF>(Hs, cs, hS);
+  NODE_STAMP(2);   // state rows arrived and stored
   __syncthreads();
+  NODE_STAMP(3);
   if (Ks > 0) {
     chunk_mfma<NRT, 0, true, BF>(Hs, rt0, j, kq, wr, wp, gStride, 4, gLast, acc);
+    NODE_STAMP(4);   // chunk 0 issued
     chunk_store<ROWS, BF>(Gb, cs, st[1]);
     if (Ks > 1) chunk_store<ROWS, BF>(Gb + CH, cs, st[0]);
     chunk_load<ROWS>(cs, Ks, 3, st[1]);
     chunk_load<ROWS>(cs, Ks, 4, st[0]);
+    NODE_STAMP(5);   // chunks 1, 2 arrived and stored
     __syncthreads();
+    NODE_STAMP(6);
     for (int c = 1; c < Ks; c += 2) {
       // odd chunk c (not the last) in Gb[0]; afterwards Gb[0] <- chunk c+2 (waiting in st[1])
       chunk_mfma<NRT, 1, true, BF>(Gb, rt0, j, kq, wr, wp, gStride, 4 * (c + 1), gLast, acc);
+      NODE_STAMP(7);   // (the last odd chunk's)
       __syncthreads();
+      NODE_STAMP(8);
       if (c + 2 <= Ks) chunk_store<ROWS, BF>(Gb, cs, st[1]);
       chunk_load<ROWS>(cs, Ks, c + 4, st[1]);
       if (c + 1 < Ks) {  // even chunk c+1 (not the last) in Gb[1]; afterwards Gb[1] <- chunk c+3 (waiting in st[0])
         chunk_mfma<NRT, 0, true, BF>(Gb + CH, rt0, j, kq, wr, wp, gStride, 4 * (c + 2), gLast, acc);
+        NODE_STAMP(9);
         __syncthreads();
+        NODE_STAMP(10);
         if (c + 3 <= Ks) chunk_store<ROWS, BF>(Gb + CH, cs, st[0]);
         chunk_load<ROWS>(cs, Ks, c + 5, st[0]);
       }
     }
   }
   late();
+  NODE_STAMP(11);  // late requests issued
   if (Ks & 1) chunk_mfma<NRT, 1, false, BF>(Gb, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);               // odd last chunk
   else chunk_mfma<NRT, 0, false, BF>(Ks > 0 ? Gb + CH : Hs, rt0, j, kq, wr, wp, gStride, 0, gLast, acc);  // even (or chunk 0)
+  NODE_STAMP(12);  // last chunk issued
 }
 
 // layer-0 x part: acc[q] += XA[rows of tile rt0+q][16 gx .. +16] . Wx[gx]; A fragments come straight from global
@@ -343,6 +423,7 @@ inline unsigned node_items(int N, int rows, int blockRows) {
 template <bool SAVE, int ROWS, bool BF = false>
 __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES_GATE : NODE_MIN_WAVES_32) void k_gate16(Node16Args a) {
   typedef typename NodeOp<BF>::T Op;
+  static_assert(!(SAVE && BF), "the training forward runs fp32 operands");
   constexpr int NRT = ROWS / 16, CH = ROWS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;               // [ROWS][16 slots] the state rows: chunk 0, and the h of z*h
@@ -351,13 +432,15 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES_GATE : NODE_MIN_WA
   if (!node_item(blockIdx.x, (a.rows + ROWS - 1) / ROWS, a.N, n, rbr)) return;
   const int rowBase = rbr * ROWS;
   const int RB = (a.rows + 63) >> 6, rb = rowBase >> 6, rtb = (rowBase & 63) >> 4;   // 64-row block of PX / R, first row tile in it
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + a.Ks);
   const size_t gStride = 8 * 64;
   const Op* wp = reinterpret_cast<const Op*>(a.w) + ((size_t)n * (nG + a.nGx) * 8 + w) * 64 + lane;
   f32x4 acc[NRT];
   float4 pxv[NRT];               // hoisted pre-activation (x rows + bias) in fragment order, added in the epilogue
   float hz[BF ? NRT : 1][4];     // BF: the fp32 state values of z*h (the LDS copy is rounded to bf16), requested late
+  NODE_STAMP_DECL
+  NODE_STAMP(0);
   node_k_loop<ROWS, NRT, BF>(a, n, rowBase, Hs, Gb, 0, j, kq, wp, gStride, acc, [&]() {
     if constexpr (BF) {
       if (w < 4) {
@@ -377,48 +460,85 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES_GATE : NODE_MIN_WA
       for (int rt = 0; rt < NRT; ++rt) pxv[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
       x_groups<NRT, BF>(a, n, rowBase, 0, wp + (size_t)nG * gStride, gStride, j, kq, acc);
     }
-  });
+  } NODE_STAMP_ARG);
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) {
     acc[rt][0] += pxv[rt].x; acc[rt][1] += pxv[rt].y; acc[rt][2] += pxv[rt].z; acc[rt][3] += pxv[rt].w;
   }
+  NODE_STAMP(13);  // accumulators + PX ready
   // epilogue: zr = sigmoid(.);  r leaves in fragment order straight from the accumulators (the update kernel of
-  // this node reads it back the same way); z*h is gathered as a [ROWS][64] tile in LDS (the chunk buffers are dead once
-  // every wave has left the K loop) and written out as whole 256-byte rows of the next mix's operand
+  // this node reads it back the same way); z is gathered as a [ROWS][64] tile in LDS (the chunk buffers are dead once
+  // every wave has left the K loop), and z*h leaves as whole 256-byte rows of the next mix's operand: the row sweep
+  // multiplies the z tile with the state tile, float4 by float4.
+  // (Round 4: this stretch used to read h and write z*h element by element behind exec-masked branches on the wave
+  // index - one exposed LDS round trip per element; the wave index is now provably uniform, the 16 sigmoids of a lane
+  // are independent, and the LDS sees 16 scalar writes and 2 wide reads per thread.  The training instantiation keeps
+  // an r tile too and saves z and r as float4 rows instead of 64-byte pieces.)
   __syncthreads();
-  float* Out = Gb;
+  NODE_STAMP(14);
+  float* Zt = Gb;                // z tile (BF: z*h, the LDS state copy is bf16 there)
+  float* Rt = Gb + CH;           // SAVE: r tile
   const int o = 16 * w + j;
+  if (a.raw) {                   // unit entry point: pre-activation dump
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int lb = rt * 16 + 4 * kq + e, b = rowBase + lb;
-      const float v = acc[rt][e];
-      if (a.raw && b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = v;
-      const float sg = sigmoid16(v);
-      if (SAVE && b < a.rows) ((w < 4) ? a.svZ : a.svR)[((size_t)b * a.Np + n) * 64 + (o & 63)] = sg;
-      if (w < 4) {
-        if constexpr (BF) Out[swz(lb, o, 16)] = sg * hz[rt][e];
-        else Out[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
-      } else {
-        acc[rt][e] = sg;
+      for (int e = 0; e < 4; ++e) {
+        const int b = rowBase + rt * 16 + 4 * kq + e;
+        if (b < a.rows) a.raw[((size_t)b * a.N + n) * 128 + o] = acc[rt][e];
       }
-    }
   }
-  if (w >= 4) {
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[rt][e] = sigmoid16(acc[rt][e]);
+  if (w < 4) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lb = rt * 16 + 4 * kq + e;
+        if constexpr (BF) Zt[swz(lb, o, 16)] = acc[rt][e] * hz[rt][e];
+        else Zt[swz(lb, o, 16)] = acc[rt][e];
+      }
+  } else {
     const size_t base = (((((size_t)n * RB + rb) * 4 + (w - 4)) * 4) + rtb) * 256 + (size_t)lane * 4;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
       store_wt16(a.r, base + (size_t)rt * 256, make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]));
+    if constexpr (SAVE) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Rt[swz(rt * 16 + 4 * kq + e, o - 64, 16)] = acc[rt][e];
+    }
   }
+  NODE_STAMP(15);  // sigmoids done, tiles in LDS
   __syncthreads();
+  NODE_STAMP(16);
 #pragma unroll
   for (int it = 0; it < ROWS / 32; ++it) {          // ROWS rows x 16 slots float4 over 512 threads
     const int lb = (tid >> 4) + 32 * it, q = tid & 15, b = rowBase + lb;
     if (b >= a.rows) continue;
-    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (q ^ (lb & 15))) * 4]);
+    const int at = (lb * 16 + (q ^ (lb & 15))) * 4;
+    const float4 z = *reinterpret_cast<const float4*>(&Zt[at]);
+    float4 v = z;
+    if constexpr (!BF) {
+      const float4 h = *reinterpret_cast<const float4*>(&Hs[at]);
+      v = make_float4(z.x * h.x, z.y * h.y, z.z * h.z, z.w * h.w);
+    }
     store_wt16(a.zh, ((size_t)b * a.Np + n) * 64 + q * 4, v);
+    if constexpr (SAVE) {
+      *reinterpret_cast<float4*>(a.svZ + ((size_t)b * a.Np + n) * 64 + q * 4) = z;
+      *reinterpret_cast<float4*>(a.svR + ((size_t)b * a.Np + n) * 64 + q * 4) = *reinterpret_cast<const float4*>(&Rt[at]);
+    }
   }
+  NODE_STAMP(17);  // stores issued
+#ifdef NODE_LAB_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
+  NODE_STAMP(18);
+#endif
+  NODE_STAMP_FLUSH(a);
 }
 
 // ---- hoisted x part of layers >= 1: PX[t][n][rb] = bias[n] + [x | mix_k(x)] . Wx[n], fragment order ---------------
@@ -482,7 +602,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   const int n = grp * 8 + (rem & 7), blk = rem >> 3;
   if (n >= p.N) return;
   const int tl = blk / RB, rb = blk - tl * RB, rowBase = rb * 64;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + p.Ks);
   const bool two = w < 4;                       // this wave also owns column tile w + 8
   const float4* wp0 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
@@ -562,14 +682,42 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
   float* ZH2 = Gb;               //   [ROWS][16 slots] z2*h'
   float* R2 = Gb + CH;           //   [ROWS][16 slots] r2
   float* XT = lds + 3 * CH;      // [ROWS][16 slots] x_t (zero padded); afterwards the output tile
+  float* SV = lds + 4 * CH;      // SAVE only (80 KB of LDS): the tile an activation passes through on its way to the
+                                 // training buffer - hc, then z2 - so that it is saved as float4 rows (round 4; scalar
+                                 // stores from the accumulator layout were 64-byte pieces, +1.1 ms per training forward)
+  static_assert(!(SAVE && BF), "the training forward runs fp32 operands");
   int n, rbr;
   if (!node_item(blockIdx.x, (a.rows + ROWS - 1) / ROWS, a.N, n, rbr)) return;
   const int rowBase = rbr * ROWS;
   const int RB = (a.rows + 63) >> 6, rb = rowBase >> 6, rtb = (rowBase & 63) >> 4;   // 64-row block of PX / R, first row tile in it
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
   const int ct = w & 3, rh = w >> 2;
   const int srow = tid >> 4, sq = tid & 15;   // staging coordinates: 32 rows x 16 slots per sweep
   const int o4 = 16 * ct + j;                 // column of this lane in a 64-wide tile
+  NODE_STAMP_DECL
+  // the residual cell's x_t rows of this thread's staging slots (zero padded to Cpad); MODE 1 requests them before the
+  // last K chunk - requested after the update's epilogue, their whole memory latency sat between two barriers with the
+  // matrix pipe idle (round 4 stamps: 10 k cycles for that stretch)
+  float4 xv[NS];
+  auto request_xt = [&]() {
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+      const int rr = srow + 32 * it;
+      const size_t xrow = (size_t)min(rowBase + rr, a.rows - 1) * a.xRowStride;
+      if (a.C == 64) {
+        xv[it] = *reinterpret_cast<const float4*>(a.xt + xrow + (size_t)n * 64 + sq * 4);
+      } else {
+        float e4[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = min(sq * 4 + cc, a.C - 1);
+          const float v = a.xt[xrow + (size_t)n * a.C + c];
+          e4[cc] = (sq * 4 + cc < a.C) ? v : 0.f;
+        }
+        xv[it] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+      }
+    }
+  };
 
   if (MODE != 2) {
     const int nG = 4 * (1 + a.Ks);
@@ -580,6 +728,7 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     // the previous state row-major
     float4 pxv[NR2], rv[NR2];
     float hv[NR2][4];
+    NODE_STAMP(0);
     node_k_loop<ROWS, NR2, BF>(a, n, rowBase, Hs, Gb, NR2 * rh, j, kq, wp, gStride, acc, [&]() {
       if (a.px) {
         const float4* pf = reinterpret_cast<const float4*>(a.px) +
@@ -601,21 +750,26 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
           const int b = min(rowBase + (NR2 * rh + q) * 16 + 4 * kq + e, a.rows - 1);
           hv[q][e] = a.h[((size_t)b * a.Np + n) * 64 + o4];
         }
-    });
+#if NODE_XT_LATE
+      if (MODE == 1) request_xt();
+#endif
+    } NODE_STAMP_ARG);
 #pragma unroll
     for (int q = 0; q < NR2; ++q) {
       acc[q][0] += pxv[q].x; acc[q][1] += pxv[q].y; acc[q][2] += pxv[q].z; acc[q][3] += pxv[q].w;
     }
+    NODE_STAMP(13);
     __syncthreads();   // every wave is out of the K loop: Hs (z*h) may be overwritten by h'
+    NODE_STAMP(14);
 #pragma unroll
     for (int q = 0; q < NR2; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int lb = (NR2 * rh + q) * 16 + 4 * kq + e, b = rowBase + lb;
-        const float hc = tanhf(acc[q][e]);
+        const float hc = tanh16(acc[q][e]);
         const float rr = e == 0 ? rv[q].x : e == 1 ? rv[q].y : e == 2 ? rv[q].z : rv[q].w;
         float hn = rr * hv[q][e] + (1.0f - rr) * hc;   // (MultiATGCN.py:127: r blends, z gated the candidate)
-        if (SAVE && b < a.rows) a.svHC[((size_t)b * a.Np + n) * 64 + o4] = hc;
+        if constexpr (SAVE) SV[swz(lb, o4, 16)] = hc;   // saved as float4 rows behind the next barrier
         if (b >= a.rows) hn = 0.f;
         if (MODE == 0) { if (b < a.rows) a.hout[((size_t)b * a.Np + n) * 64 + o4] = hn; }
         else Hs[swz(lb, o4, 16)] = hn;                  // h' tile for the residual cell (z*h no longer needed)
@@ -637,24 +791,12 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
   // ---- residual GRU cell on [x_t | h'] (MultiATGCN.py:142-150) ----
   const int ngx = a.Cpad >> 4;                     // x groups of the residual GEMMs (1 or 4)
   const int nG1 = ngx + 4;                         // <= 8
+  if (MODE != 1 || !NODE_XT_LATE) request_xt();
 #pragma unroll
   for (int it = 0; it < NS; ++it) {   // x_t tile (zero padded to Cpad)
     const int rr = srow + 32 * it;
-    const bool ok = rowBase + rr < a.rows;
-    const size_t xrow = (size_t)min(rowBase + rr, a.rows - 1) * a.xRowStride;
-    if (a.C == 64) {
-      const float4 xv = *reinterpret_cast<const float4*>(a.xt + xrow + (size_t)n * 64 + sq * 4);
-      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(ok, xv);
-    } else if (sq < (a.Cpad >> 2)) {
-      float e4[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = min(sq * 4 + cc, a.C - 1);
-        const float xv = a.xt[xrow + (size_t)n * a.C + c];
-        e4[cc] = (ok && sq * 4 + cc < a.C) ? xv : 0.f;
-      }
-      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-    }
+    if (a.C == 64 || sq < (a.Cpad >> 2))
+      *reinterpret_cast<float4*>(&XT[(rr * 16 + (sq ^ (rr & 15))) * 4]) = keep4(rowBase + rr < a.rows, xv[it]);
   }
   // weights of both residual GEMMs (shared by all nodes, L2-resident), requested before the tile barrier
   const int rp = rh;
@@ -665,8 +807,19 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     for (int g = 0; g < 8; ++g) rgv[g] = rgp[(size_t)min(g, nG1 - 1) * 8 * 64];
   }
   const float bg = a.rgb[16 * w + j], bu = a.rub[o4];
-  const float gate = a.blend ? sigmoid16(a.blend[0]) : 0.f;   // g = sigmoid(weights_gru[l][t]) (:208)
+  const float gate = a.blend ? sigmoid_f(a.blend[0]) : 0.f;   // g = sigmoid(weights_gru[l][t]) (:208); the backward's form
+  NODE_STAMP(15);  // tanh + blend done, h' and x_t tiles stored
   __syncthreads();
+  NODE_STAMP(16);
+  if constexpr (SAVE && MODE == 1) {   // hc rows -> training buffer (SV is rewritten only behind the NEXT barrier)
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+      const int lb = srow + 32 * it, b = rowBase + lb;
+      if (b < a.rows)
+        *reinterpret_cast<float4*>(a.svHC + ((size_t)b * a.Np + n) * 64 + sq * 4) =
+            *reinterpret_cast<const float4*>(&SV[(lb * 16 + (sq ^ (lb & 15))) * 4]);
+    }
+  }
   // GEMM 1: zr2 = sigmoid([x|h'] Wg + bg): wave w = column tile w (of 8), all row tiles
   f32x4 acc1[NRT];
 #pragma unroll
@@ -698,20 +851,43 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     for (int g = 0; g < 8; ++g) ruv[g] = rup[(size_t)min(g, nG1 - 1) * 4 * 64];
   }
   {
+    // (round 4: the h' values a z2 wave multiplies by are read in one batch - 16 exposed LDS round trips before)
     const int o = 16 * w + j;
+    float hp1[NRT][4];
+    if (w < 4) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hp1[rt][e] = Hs[swz(rt * 16 + 4 * kq + e, o, 16)];
+    }
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int lb = rt * 16 + 4 * kq + e;
-        const float sg = sigmoid16(acc1[rt][e] + bg);
-        if (SAVE && rowBase + lb < a.rows)
-          ((w < 4) ? a.svZ2 : a.svR2)[((size_t)(rowBase + lb) * a.Np + n) * 64 + (o & 63)] = sg;
-        if (w < 4) ZH2[swz(lb, o, 16)] = sg * Hs[swz(lb, o, 16)];
-        else R2[swz(lb, o - 64, 16)] = sg;
-      }
+      for (int e = 0; e < 4; ++e) acc1[rt][e] = sigmoid16(acc1[rt][e] + bg);
+    if (w < 4) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ZH2[swz(rt * 16 + 4 * kq + e, o, 16)] = acc1[rt][e] * hp1[rt][e];
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R2[swz(rt * 16 + 4 * kq + e, o - 64, 16)] = acc1[rt][e];
+    }
   }
+  NODE_STAMP(17);  // residual GEMM 1 + sigmoids
   __syncthreads();
+  NODE_STAMP(18);
+  if constexpr (SAVE) {   // every thread is past its hc rows: SV <- z2 (kept in the z2 waves' accumulators)
+    if (w < 4) {
+      const int o = 16 * w + j;
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) SV[swz(rt * 16 + 4 * kq + e, o, 16)] = acc1[rt][e];
+    }
+  }
   // GEMM 2: hc2 = tanh([x | z2*h'] Wu + bu): wave (ct, rp) -> column tile ct, the row tiles of half rp
   f32x4 acc2[NR2];
 #pragma unroll
@@ -738,29 +914,50 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
   }
   // the new state is gathered as a [ROWS][64] tile in LDS (over x_t, dead once every wave has left GEMM 2) and
   // written to the state and to Seq_l[t] as whole 256-byte rows
+  NODE_STAMP(19);  // residual GEMM 2 issued
   __syncthreads();
   float* Out = XT;
+  float* HC2t = ZH2;             // SAVE: hc2 tile (z2*h' is dead once every wave has left GEMM 2)
+  {
+    float hp2[NR2][4], rr2[NR2][4];   // read in one batch (round 4), then the tanhs, then the writes
 #pragma unroll
-  for (int q = 0; q < NR2; ++q)
+    for (int q = 0; q < NR2; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int lb = (NR2 * rp + q) * 16 + 4 * kq + e;
-      const float hc = tanhf(acc2[q][e] + bu);
-      if (SAVE && rowBase + lb < a.rows) a.svHC2[((size_t)(rowBase + lb) * a.Np + n) * 64 + o4] = hc;
-      const float hp = Hs[swz(lb, o4, 16)];
-      const float rr = R2[swz(lb, o4, 16)];
-      const float res = rr * hp + (1.0f - rr) * hc;
-      Out[swz(lb, o4, 16)] = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int lb = (NR2 * rp + q) * 16 + 4 * kq + e;
+        hp2[q][e] = Hs[swz(lb, o4, 16)];
+        rr2[q][e] = R2[swz(lb, o4, 16)];
+      }
+#pragma unroll
+    for (int q = 0; q < NR2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc2[q][e] = tanh16(acc2[q][e] + bu);
+#pragma unroll
+    for (int q = 0; q < NR2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lb = (NR2 * rp + q) * 16 + 4 * kq + e;
+        const float hc = acc2[q][e], hp = hp2[q][e], rr = rr2[q][e];
+        if constexpr (SAVE) HC2t[swz(lb, o4, 16)] = hc;
+        const float res = rr * hp + (1.0f - rr) * hc;
+        Out[swz(lb, o4, 16)] = a.blend ? (gate * hp + (1.0f - gate) * res) : res;
+      }
+  }
+  NODE_STAMP(20);  // tanh + blends
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < NS; ++it) {                 // ROWS rows x 16 slots float4 over 512 threads
     const int lb = srow + 32 * it, b = rowBase + lb;
     if (b >= a.rows) continue;
-    const float4 v = *reinterpret_cast<const float4*>(&Out[(lb * 16 + (sq ^ (lb & 15))) * 4]);
+    const int at = (lb * 16 + (sq ^ (lb & 15))) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(&Out[at]);
     store_wt16(a.hout, ((size_t)b * a.Np + n) * 64 + sq * 4, v);
     if (a.seq) store_wt16(a.seq, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4, v);
     if constexpr (SAVE) {
+      const size_t sat = ((size_t)b * a.Np + n) * 64 + sq * 4;
+      *reinterpret_cast<float4*>(a.svZ2 + sat) = *reinterpret_cast<const float4*>(&SV[at]);
+      *reinterpret_cast<float4*>(a.svR2 + sat) = *reinterpret_cast<const float4*>(&R2[at]);
+      *reinterpret_cast<float4*>(a.svHC2 + sat) = *reinterpret_cast<const float4*>(&HC2t[at]);
       if (a.seqDrop) {
         const float4 m = *reinterpret_cast<const float4*>(a.dropMask + (size_t)b * a.dropRowStride + (size_t)n * 64 + sq * 4);
         *reinterpret_cast<float4*>(a.seqDrop + (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4) =
@@ -768,6 +965,11 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
       }
     }
   }
+#ifdef NODE_LAB_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  NODE_STAMP(21);
+#endif
+  NODE_STAMP_FLUSH(a);
 }
 
 // bf16 copy of a fragment-ordered weight stream (same indexing, half the bytes): 8 floats per thread
