@@ -366,6 +366,9 @@ struct LayerBufs {
   [[maybe_unused]] float* DH = tr + R.oDH[par]; [[maybe_unused]] float* DHa = tr + R.oDHa[par];                     \
   [[maybe_unused]] float* TMP = tr + R.oTmp[par]; [[maybe_unused]] float* MixOut = tr + R.oMixOut[par]
 
+#ifndef CHAIN_FUSE_RES_NODE
+#define CHAIN_FUSE_RES_NODE 1   // 0: round 3's pair k_chain_res_fused + k_chain_node<false, 64> (A/B builds)
+#endif
 // scratch and outputs start from zero (only what is accumulated into, or what the GEMMs leave untouched)
 int bwd_clear(Pass& pass) {
   PASS_LOCALS(pass);
@@ -396,6 +399,19 @@ int bwd_clear(Pass& pass) {
     hipLaunchKernelGGL(k_zero_pad_rows_multi, dim3(blocks_for((size_t)rowsTB * S * (Np - N) * H / 4), (unsigned)nb),
                        dim3(256), 0, s, bufs, rowsTB * S, N, Np, H);
     CHECK_LAUNCH();
+  }
+  if (CHAIN_FUSE_RES_NODE && !P.gcnOff) RETURN_IF(zero_async(tr + R.oZeroSlab, slab, s));
+  if (CHAIN_FUSE_RES_NODE && Np != N && !P.gcnOff) {
+    // k_chain_res_node writes the rows of the real nodes only; DPU2 / DPG2 are summed over ALL rows by the residual
+    // nn.Linear gradients (column sums, weight GEMMs): the rows of the padding nodes must read as zero
+    for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * (Np - N) * H)), dim3(256), 0, s, tr + R.oDPU2[q],
+                         rowsTB, N, Np, H);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)rowsTB * (Np - N) * 2 * H)), dim3(256), 0, s, tr + R.oDPG2[q],
+                         rowsTB, N, Np, 2 * H);
+      CHECK_LAUNCH();
+    }
   }
   auto zero_grad = [&](float* p, long n) { return p ? zero_async(p, n, s) : MATGCN_OK; };
   RETURN_IF(zero_grad(g->node_emb, (long)N * P.d));
@@ -440,6 +456,14 @@ int plain_operands(const Ctx& c, float* tr, hipStream_t s) {
       }
       CHECK_LAUNCH();
     }
+  // fragment-ordered transposes of the residual cell's nn.Linear weights (hidden columns): k_chain_res_node's B operands
+  for (int l = 0; l < P.L && !P.gcnOff; ++l) {
+    const int I = P.Cl[l] + H;
+    hipLaunchKernelGGL(k_prep_linear_t16, dim3(4), dim3(256), 0, s, c.prm->res_update[l].weight, I, P.Cl[l], 64, tr + R.oRUf[l]);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_linear_t16, dim3(8), dim3(256), 0, s, c.prm->res_gate[l].weight, I, P.Cl[l], 128, tr + R.oRGf[l]);
+    CHECK_LAUNCH();
+  }
   return MATGCN_OK;
 }
 
@@ -648,7 +672,35 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
       if (t == T - 1 || (t + 1) % pass.chunk == 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][t / pass.chunk * pass.chunk], 0));
       if (t > 0 && t % pass.chunk == 0) HIP_OK(hipStreamWaitEvent(s, g_wf.bxcol[l + 1][t - pass.chunk], 0));
     }
-    {  // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
+    ChainNodeArgs cn;
+    memset(&cn, 0, sizeof(cn));
+    cn.c = a; cn.I = I; cn.iOfs = C; cn.rows = B; cn.N = N; cn.Np = Np; cn.S = S;
+    const dim3 ngrid((unsigned)((B + 63) / 64), (unsigned)N);
+    const bool fused = CHAIN_FUSE_RES_NODE && a.mixParts <= 4;
+    if (fused && !a.hprev) { a.hprev = tr + R.oZeroSlab; cn.c.hprev = a.hprev; }
+    if (fused) {
+      // blend + residual cell + graph-cell output algebra of step t, the carry of step t+1, and the update block's node
+      // contraction dA_u = dpu . WpU^T (h columns), one workgroup per node (round 4; more than four partial mixes - more
+      // than four dense stack slots - take round 3's pair of kernels below)
+      ChainResNodeArgs f;
+      f.c = a;
+      f.c.dcarry = (t == T - 1) ? nullptr : DH;
+      f.carryA = (t == T - 1) ? nullptr : DAg + (at + slab) * S;
+      f.carryMix = (t == T - 1 || P.Ks <= 0) ? nullptr : MixOut;
+      f.ruf = tr + R.oRUf[l]; f.rgf = tr + R.oRGf[l];
+      f.Wp = WpU; f.dA = DAu + at * S; f.I = I; f.iOfs = C;
+      const bool carry = t != T - 1;
+      const int parts = (carry && f.carryMix) ? a.mixParts : 0;
+#define CRN_LAUNCH(C_, P_) hipLaunchKernelGGL((k_chain_res_node<C_, true, P_>), ngrid, dim3(512), CRN_LDS, s, f)
+      if (!carry) CRN_LAUNCH(false, 0);
+      else switch (parts) {
+        case 0: CRN_LAUNCH(true, 0); break; case 1: CRN_LAUNCH(true, 1); break; case 2: CRN_LAUNCH(true, 2); break;
+        case 3: CRN_LAUNCH(true, 3); break; default: CRN_LAUNCH(true, 4); break;
+      }
+#undef CRN_LAUNCH
+      CHECK_LAUNCH();
+    } else {
+      // blend + residual cell + graph-cell output algebra of step t, and the carry of step t+1, in one kernel
       FusedResArgs f;
       f.c = a;
       f.c.dcarry = (t == T - 1) ? nullptr : DH;
@@ -657,21 +709,31 @@ int bwd_chain(Pass& pass, const LayerBufs& L) {
       f.ruh = RU + C; f.rgh = RG + C; f.ldW = I;
       hipLaunchKernelGGL(k_chain_res_fused<64>, dim3((unsigned)(((long)B * Np + 63) / 64)), dim3(256), fusedLds, s, f);
       CHECK_LAUNCH();
+      // update block: dA_u = dpu . WpU^T (h columns), then its transposed mix
+      cn.dPre = DPU + at; cn.Wp = WpU; cn.dA = DAu + at * S; cn.beta = 0.f;
+      hipLaunchKernelGGL((k_chain_node<false, 64>), ngrid, dim3(512), 0, s, cn);
+      CHECK_LAUNCH();
     }
-    // update block: dA_u = dpu . WpU^T (h columns), then its transposed mix
-    ChainNodeArgs cn;
-    memset(&cn, 0, sizeof(cn));
-    cn.c = a; cn.I = I; cn.iOfs = C; cn.rows = B; cn.N = N; cn.Np = Np; cn.S = S;
-    const dim3 ngrid((unsigned)((B + 63) / 64), (unsigned)N);
-    cn.dPre = DPU + at; cn.Wp = WpU; cn.dA = DAu + at * S; cn.beta = 0.f;
-    hipLaunchKernelGGL((k_chain_node<false, 64>), ngrid, dim3(512), 0, s, cn);
-    CHECK_LAUNCH();
     RETURN_IF(mix_transposed(b, DAu + at * S, B, H, MixOut, true, slab));
     // gate block: the gate algebra (prologue) and dA_g = dpg . WpG^T in one kernel, then its transposed mix
     // (below the top layer the block already holds the x-column gradient of the layer above for the step before:
     // same mix input h_{t-1}, so both ride the same transposed mix, carry and adjacency gradient)
     cn.dPre = nullptr; cn.Wp = WpG; cn.dA = DAg + at * S; cn.beta = mergeAbove ? 1.f : 0.f;
-    hipLaunchKernelGGL((k_chain_node<true, 128>), ngrid, dim3(512), 0, s, cn);
+    if (fused) {
+      const int parts = P.Ks > 0 ? a.mixParts : 0;
+#define CGN_LAUNCH(P_)                                                                                     \
+  do {                                                                                                     \
+    if (mergeAbove) hipLaunchKernelGGL((k_chain_gate_node<P_, true>), ngrid, dim3(512), 0, s, cn);         \
+    else hipLaunchKernelGGL((k_chain_gate_node<P_, false>), ngrid, dim3(512), 0, s, cn);                   \
+  } while (0)
+      switch (parts) {
+        case 0: CGN_LAUNCH(0); break; case 1: CGN_LAUNCH(1); break; case 2: CGN_LAUNCH(2); break;
+        case 3: CGN_LAUNCH(3); break; default: CGN_LAUNCH(4); break;
+      }
+#undef CGN_LAUNCH
+    } else {
+      hipLaunchKernelGGL((k_chain_node<true, 128>), ngrid, dim3(512), 0, s, cn);
+    }
     CHECK_LAUNCH();
     RETURN_IF(mix_transposed(b, DAg + at * S, B, H, MixOut, true, slab));   // the carry itself is formed by the next step's kernel
     if (l > 0 && t % pass.chunk == 0) {   // a chunk of steps is through: its x columns start beside the rest of the chain

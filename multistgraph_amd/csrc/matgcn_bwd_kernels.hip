@@ -807,6 +807,13 @@ struct FusedResArgs {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p, size_t idx) { return *reinterpret_cast<const float4*>(p + idx); }
+// 32-bit BYTE offsets from a wave-uniform base: global_load / global_store with an SGPR base and one offset VGPR
+__device__ __forceinline__ float4 ld4b(const float* p, unsigned byteOfs) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + byteOfs);
+}
+__device__ __forceinline__ void st4b(float* p, unsigned byteOfs, const float4& v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(p) + byteOfs) = v;
+}
 __device__ __forceinline__ float get4(const float4& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : x == 2 ? v.z : v.w; }
 
 // ROWS rows per workgroup (64, or 32: twice the workgroups - the kernel streams ~120 MB per launch and 416 workgroups of
@@ -1015,6 +1022,272 @@ __global__ __launch_bounds__(256) void k_dh0_out(const float* __restrict__ dh, c
   out[idx] = v;
 }
 
+// ---- round 4: the row-local part of the chain AND the update block's node contraction, one workgroup per node ---------
+// k_chain_res_fused (above) walked the rows [b][n] in blocks of 64 consecutive rows.  Its element-wise phases between the
+// two nn.Linear contractions ran in the MFMA accumulator layout: 4-byte accesses behind per-element row guards, i.e. one
+// EXPOSED memory round trip per element and phase (the ISA waits on vmcnt(0) 16 times per phase), 26 slab passes, 8 % of
+// the matrix pipe, 44 us per launch - and the node contraction of the update block then re-read dpu as a launch of its own.
+// Here a workgroup owns ONE node and 64 batch rows (the forward node kernels' work item): every global access is a float4
+// of a 256-byte row piece in the row layout (thread = row x 16-byte slot), requested in one batch per phase; the two
+// nn.Linear products and the node contraction take their A operands from swizzled LDS tiles (ds_read_b128, a float4 = four
+// reduction steps) and hand their results back to the row layout through LDS; what a row needs across the phases (dha,
+// z2, h, r, hc, ..) stays in registers.  The B operands of the nn.Linear products are fragment-ordered transposes made
+// once per parameter update (k_prep_linear_t16), those of the node contraction the plain folded weights of the node.
+//   in : dseq (+ carry of step t+1 = dh + slot 0 of the gate block's dA + its transposed mix), hprev, r, hc, r2, z2, hc2
+//   out: dpu2, dpg2 (kept for the batched part), dpu (kept), dr, dh (partial), blend-scalar gradient,
+//        dA_u[b][s][n][0:64] = dpu[b][n][:] . WpU[n][s][C + i][:]   for every kept slot s
+// Rows of the padding nodes are never touched: the caller keeps them zero where a consumer sums over all rows (DPU2, DPG2).
+struct ChainResNodeArgs {
+  ChainArgs c;
+  const float* carryA;   // dA of the gate AGCN of step t+1 ([B][S][Np][64], slot 0 is read) or null
+  const float* carryMix; // its transposed mix [parts][B][Np][64] or null
+  const float* ruf;      // [4 g][4 ct][64][4]  B fragments of d(z2 ha) = dpu2 . RU[:, C:]   (k = o, n = i)
+  const float* rgf;      // [8 g][4 ct][64][4]  B fragments of dha    += dpg2 . RG[:, C:]
+  const float* Wp;       // plain folded weights of the update AGCN [N][S][I][64]
+  float* dA;             // [B][S][Np][64]
+  int I, iOfs;
+};
+
+// nn.Linear weight W (O, I), columns C.. = the 64 hidden inputs: out[g][ct][lane][s] = W[16 g + 4 (lane >> 4) + s][C + 16 ct + (lane & 15)]
+__global__ __launch_bounds__(256) void k_prep_linear_t16(const float* __restrict__ W, int I, int C, int O, float* __restrict__ out) {
+  const int unit = blockIdx.x * 256 + threadIdx.x;
+  if (unit >= (O / 16) * 4 * 64) return;
+  const int lane = unit & 63, ct = (unit >> 6) & 3, g = unit >> 8;
+  float v[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) v[s4] = W[(size_t)(16 * g + 4 * (lane >> 4) + s4) * I + C + 16 * ct + (lane & 15)];
+  *reinterpret_cast<float4*>(out + (size_t)unit * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+#define CRN_LDS (3 * 4096 * (int)sizeof(float))
+__device__ __forceinline__ float4 f4_add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_mul(const float4& a, const float4& b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// CARRY: step t+1 exists (dcarry, carryA and PARTS partial transposed mixes are added to the incoming gradient); HPREV: h_{t-1}
+// exists.  Template parameters, not runtime branches: a request behind a branch ends a basic block and the compiler drains the
+// whole queue (vmcnt(0)) where the paths meet - phase 1 is ONE batch of 8 + 2 + PARTS requests per row sweep.
+template <bool CARRY, bool HPREV, int PARTS>
+__global__ __launch_bounds__(512, 4) void k_chain_res_node(ChainResNodeArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* R0 = lds;             // dpu2 tile -> z half of dpg2 -> dpu tile
+  float* R1 = lds + 4096;      // r half of dpg2 -> output tile 0 of the node contraction
+  float* R2 = lds + 8192;      // GEMM results on their way back to the row layout -> output tile 1
+  __shared__ float red[8];
+  const ChainArgs& a = f.c;
+  const int n = blockIdx.y, rowBase = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+  const int ct = w & 3, rh = w >> 2;
+  const int srow = tid >> 4, sq = tid & 15;
+  const float g = sigmoid_f(a.blend[0]);
+  // ---- phase 1, row layout (one batch of requests per row sweep; 32-bit byte offsets: SGPR base + one VGPR) ----
+  float4 dha0[2], c1v[2], z2k[2];
+  float part = 0.f;
+  {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int b = rowBase + srow + 32 * it;
+      const bool ok = b < a.B;
+      const unsigned bb = (unsigned)min(b, a.B - 1);
+      const unsigned ob = ((bb * a.Np + n) * 64 + sq * 4) * 4u;       // byte offset of this thread's float4 in a [B][Np][64] slab
+      float4 d = ld4b(a.dseq, ob);
+      const float4 hv = HPREV ? ld4b(a.hprev, ob) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 rv = ld4b(a.r, ob), hcv = ld4b(a.hc, ob), r2v = ld4b(a.r2, ob), hc2v = ld4b(a.hc2, ob);
+      z2k[it] = ld4b(a.z2, ob);
+      if constexpr (CARRY) {
+        const float4 cry = ld4b(a.dcarry, ob), cA = ld4b(f.carryA, (((bb * a.S) * a.Np + n) * 64 + sq * 4) * 4u);
+        float4 cM[PARTS > 0 ? PARTS : 1];
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) cM[pt] = ld4b(f.carryMix + (size_t)pt * a.mixPartStride, ob);
+        d = f4_add(d, f4_add(cry, cA));
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) d = f4_add(d, cM[pt]);
+      }
+      float dpu2[4], drr[4], dh0[4], c1[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float dd = get4(d, x), h = get4(hv, x), r = get4(rv, x), hc = get4(hcv, x);
+        const float r2 = get4(r2v, x), z2 = get4(z2k[it], x), hc2 = get4(hc2v, x);
+        const float ha = r * h + (1.f - r) * hc;
+        const float res = r2 * ha + (1.f - r2) * hc2;
+        if (ok) part += dd * (ha - res);
+        const float dres = (1.f - g) * dd;
+        dh0[x] = g * dd + dres * r2;
+        dpu2[x] = dres * (1.f - r2) * (1.f - hc2 * hc2);
+        drr[x] = dres * (ha - hc2) * r2 * (1.f - r2);
+        c1[x] = ha * z2 * (1.f - z2);
+      }
+      dha0[it] = make_float4(dh0[0], dh0[1], dh0[2], dh0[3]);
+      c1v[it] = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      const float4 v2 = make_float4(dpu2[0], dpu2[1], dpu2[2], dpu2[3]), vr = make_float4(drr[0], drr[1], drr[2], drr[3]);
+      const int lr = srow + 32 * it, pos = (lr * 16 + (sq ^ (lr & 15))) * 4;
+      *reinterpret_cast<float4*>(&R0[pos]) = v2;
+      *reinterpret_cast<float4*>(&R1[pos]) = vr;
+      if (ok) {
+        st4b(a.dpu2, ob, v2);
+        st4b(a.dpg2, 2 * (ob - sq * 16) + 256 + sq * 16, vr);
+      }
+    }
+    // blend-scalar gradient: wave sums now, the workgroup's sum behind the next barriers
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (lane == 0) red[w] = part;
+  }
+  // B fragments of the nn.Linear products (shared by every workgroup: L2): the first product's before the first barrier,
+  // the second product's behind phase 2 (all twelve at once spilled phase 1's row values)
+  __builtin_amdgcn_sched_barrier(0);
+  float4 bu[4], bgf[8];
+  {
+    const float4* pu = reinterpret_cast<const float4*>(f.ruf) + (size_t)ct * 64 + lane;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bu[gq] = pu[gq * 256];
+  }
+  __syncthreads();
+  if (tid == 0 && a.dblend) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += red[q];
+    unsafeAtomicAdd(a.dblend, sum * g * (1.f - g));
+  }
+  // ---- phase 2: d(z2 ha) = dpu2 . RU[:, C:]  (wave = column tile ct x row half rh) ----
+  f32x4 acc[2];
+  auto frag = [&](const float* tile, int rt, int gq) {
+    return *reinterpret_cast<const float4*>(&tile[((rt * 16 + j) * 16 + ((4 * gq + kq) ^ j)) * 4]);
+  };
+  auto to_tile = [&](float* tile) {   // the wave's 2 x (16 x 16) results -> row-major tile
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[swz((2 * rh + q) * 16 + 4 * kq + e, 16 * ct + j, 16)] = acc[q][e];
+  };
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const float4 a0 = frag(R0, 2 * rh, gq), a1 = frag(R0, 2 * rh + 1, gq), bv = bu[gq];
+    acc[0] = MFMA16(a0.x, bv.x, acc[0]); acc[1] = MFMA16(a1.x, bv.x, acc[1]);
+    acc[0] = MFMA16(a0.y, bv.y, acc[0]); acc[1] = MFMA16(a1.y, bv.y, acc[1]);
+    acc[0] = MFMA16(a0.z, bv.z, acc[0]); acc[1] = MFMA16(a1.z, bv.z, acc[1]);
+    acc[0] = MFMA16(a0.w, bv.w, acc[0]); acc[1] = MFMA16(a1.w, bv.w, acc[1]);
+  }
+  to_tile(R2);
+  {
+    const float4* pg = reinterpret_cast<const float4*>(f.rgf) + (size_t)ct * 64 + lane;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) bgf[gq] = pg[gq * 256];
+  }
+  __syncthreads();
+  // ---- phase 3, row layout: dha += dzh2 z2; the z half of dpg2 -> global + tile (over the dpu2 tile: phase 2 is through) ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lr = srow + 32 * it, pos = (lr * 16 + (sq ^ (lr & 15))) * 4;
+    const float4 dzh2 = *reinterpret_cast<const float4*>(&R2[pos]);
+    dha0[it] = f4_add(dha0[it], f4_mul(dzh2, z2k[it]));
+    const float4 dz = f4_mul(dzh2, c1v[it]);
+    *reinterpret_cast<float4*>(&R0[pos]) = dz;
+    const int b = rowBase + lr;
+    if (b < a.B) st4b(a.dpg2, (((unsigned)b * a.Np + n) * 128 + sq * 4) * 4u, dz);
+  }
+  const int nCt = 4 * a.S;
+  auto wload = [&](int tile, int gq) -> float4 {
+    const int slot = tile >> 2, i0 = (tile & 3) * 16;
+    const size_t wrow = ((size_t)n * a.S + slot) * f.I + f.iOfs + i0 + j;
+    return (reinterpret_cast<const float4*>(f.Wp + wrow * 64) + kq)[gq * 4];
+  };
+  // what phase 5 needs again of the saved state (read in phase 1: L2 hits), in flight under phase 4
+  float4 hk[2], rk[2], hck[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const unsigned ob = (((unsigned)min(rowBase + srow + 32 * it, a.B - 1) * a.Np + n) * 64 + sq * 4) * 4u;
+    hk[it] = HPREV ? ld4b(a.hprev, ob) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rk[it] = ld4b(a.r, ob); hck[it] = ld4b(a.hc, ob);
+  }
+  __syncthreads();
+  // ---- phase 4: dha += dpg2 . RG[:, C:]  (k 0..63 the z half, 64..127 the r half) ----
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+  for (int gq = 0; gq < 8; ++gq) {
+    const float* tile = gq < 4 ? R0 : R1;
+    const float4 a0 = frag(tile, 2 * rh, gq & 3), a1 = frag(tile, 2 * rh + 1, gq & 3), bv = bgf[gq];
+    acc[0] = MFMA16(a0.x, bv.x, acc[0]); acc[1] = MFMA16(a1.x, bv.x, acc[1]);
+    acc[0] = MFMA16(a0.y, bv.y, acc[0]); acc[1] = MFMA16(a1.y, bv.y, acc[1]);
+    acc[0] = MFMA16(a0.z, bv.z, acc[0]); acc[1] = MFMA16(a1.z, bv.z, acc[1]);
+    acc[0] = MFMA16(a0.w, bv.w, acc[0]); acc[1] = MFMA16(a1.w, bv.w, acc[1]);
+  }
+  to_tile(R2);   // (phase 3 read R2 before the barrier above)
+  // the node contraction's weights of this wave's first column tile land under phase 5
+  float4 wt[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) wt[gq] = wload(min(w, nCt - 1), gq);
+  __syncthreads();
+  // ---- phase 5, row layout: graph cell output algebra (MultiATGCN.py:127); dpu -> global + tile ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lr = srow + 32 * it, pos = (lr * 16 + (sq ^ (lr & 15))) * 4;
+    const float4 dha = f4_add(dha0[it], *reinterpret_cast<const float4*>(&R2[pos]));
+    float dr4[4], dh4[4], dpu4[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float d = get4(dha, x), h = get4(hk[it], x), r = get4(rk[it], x), hc = get4(hck[it], x);
+      dr4[x] = d * (h - hc);
+      dh4[x] = d * r;
+      dpu4[x] = d * (1.f - r) * (1.f - hc * hc);
+    }
+    const float4 vpu = make_float4(dpu4[0], dpu4[1], dpu4[2], dpu4[3]);
+    *reinterpret_cast<float4*>(&R0[pos]) = vpu;
+    const int b = rowBase + lr;
+    if (b < a.B) {
+      const unsigned ob = (((unsigned)b * a.Np + n) * 64 + sq * 4) * 4u;
+      st4b(a.dr, ob, make_float4(dr4[0], dr4[1], dr4[2], dr4[3]));
+      st4b(a.dh, ob, make_float4(dh4[0], dh4[1], dh4[2], dh4[3]));
+      st4b(a.dpu, ob, vpu);
+    }
+  }
+  __syncthreads();
+  // ---- phase 6: dA_u = dpu . WpU[n]^T, column tiles w, w + 8, .. of the 4 S (slot tile >> 2, hidden columns 16 (tile & 3) ..) ----
+  const int passes = (nCt + 7) >> 3;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int tile = w + 8 * pass;
+    if (tile < nCt) {                               // wave-uniform
+      f32x4 ac[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) ac[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nextTile = min(tile + 8, nCt - 1);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float4 av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[rt] = frag(R0, rt, gq);
+        const float4 wv = wt[gq];
+        wt[gq] = wload(nextTile, gq);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ac[rt] = MFMA16(av[rt].x, wv.x, ac[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ac[rt] = MFMA16(av[rt].y, wv.y, ac[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ac[rt] = MFMA16(av[rt].z, wv.z, ac[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ac[rt] = MFMA16(av[rt].w, wv.w, ac[rt]);
+      }
+      float* tileOut = (w >> 2) ? R2 : R1;
+      const int col = (w & 3) * 16 + j;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tileOut[swz(rt * 16 + 4 * kq + e, col, 16)] = ac[rt][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int id2 = tid + 512 * q, sl = id2 >> 10, lb = (id2 >> 4) & 63, s4 = id2 & 15;
+      const int slot = 2 * pass + sl, b = rowBase + lb;
+      if (slot < a.S && b < a.B) {
+        const float4 v = *reinterpret_cast<const float4*>(&(sl ? R2 : R1)[(lb * 16 + (s4 ^ (lb & 15))) * 4]);
+        st4b(f.dA, ((((unsigned)b * a.S + slot) * a.Np + n) * 64 + 4 * s4) * 4u, v);
+      }
+    }
+    if (pass + 1 < passes) __syncthreads();
+  }
+}
+
 // ---- the chain's node contraction, dedicated kernel ----------------------------------------------------------------
 //   dA[b][s][n][i] (+)= sum_o dPre[b][n][o] * Wp[n][s][iOfs + i][o]        for the 64 hidden columns i of every slot s
 // the transpose of the forward's node-wise contraction (MultiATGCN.py:108), with the forward kernel's structure: one
@@ -1175,6 +1448,118 @@ __global__ __launch_bounds__(512, 4) void k_chain_node(ChainNodeArgs p) {
           *dst = p.beta != 0.f ? *dst + acc[rt][e] : acc[rt][e];
         }
     }
+  }
+}
+
+// ---- round 4: the gate block of the chain with its requests batched -------------------------------------------------
+// k_chain_node<true, 128> above, restated: its prologue looped over the partial transposed mixes and guarded its stores -
+// four or five dependent waits (vmcnt(0)) per row sweep - and its read-modify-write epilogue (the block already holds the
+// x-column gradient of the layer above) waited for every old value right before its store, 40 us per launch for 2 GFLOP.
+// Here the PARTS partial mixes and the presence of old values are template parameters, h_{t-1} always exists (the launcher
+// passes a zero slab at t = 0), every request of a row sweep leaves in one batch with 32-bit byte offsets from SGPR bases,
+// and the old values of a pass are requested before its MFMAs.
+template <int PARTS, bool BETA>
+__global__ __launch_bounds__(512, 4) void k_chain_gate_node(ChainNodeArgs p) {
+  constexpr int NG = 8;
+  __shared__ __attribute__((aligned(16))) float As[2 * 4096];    // [gz | gr][64 rows][16 slots], swizzled
+  __shared__ __attribute__((aligned(16))) float Out[2 * 4096];
+  const ChainArgs& a = p.c;
+  const int n = blockIdx.y, rowBase = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+  const int srow = tid >> 4, sq = tid & 15;
+  const int nCt = 4 * p.S;
+  auto wload1 = [&](int ct, int g) -> float4 {
+    const int slot = ct >> 2, i0 = (ct & 3) * 16;
+    const size_t wrow = ((size_t)n * p.S + slot) * p.I + p.iOfs + i0 + j;
+    return (reinterpret_cast<const float4*>(p.Wp + wrow * 128) + kq)[g * 4];
+  };
+  float4 wt[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) wt[g] = wload1(min(w, nCt - 1), g);
+  // ---- A tile = the gate algebra of the graph cell (MultiATGCN.py:122-125 transposed), row layout ----
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lr = srow + 32 * it, b = rowBase + lr;
+    const bool ok = b < p.rows;
+    const unsigned bb = (unsigned)min(b, p.rows - 1);
+    const unsigned ob = ((bb * p.Np + n) * 64 + sq * 4) * 4u;
+    float4 dzh = ld4b(a.dzhA, (((bb * a.S) * a.Np + n) * 64 + sq * 4) * 4u);
+    float4 mx[PARTS > 0 ? PARTS : 1];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) mx[pt] = ld4b(a.dzhMix + (size_t)pt * a.mixPartStride, ob);
+    const float4 h = ld4b(a.hprev, ob), z = ld4b(a.z, ob), r = ld4b(a.r, ob), dr = ld4b(a.dr, ob), dh = ld4b(a.dh, ob);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) dzh = f4_add(dzh, mx[pt]);
+    const float4 gz = make_float4(dzh.x * h.x * z.x * (1.f - z.x), dzh.y * h.y * z.y * (1.f - z.y),
+                                  dzh.z * h.z * z.z * (1.f - z.z), dzh.w * h.w * z.w * (1.f - z.w));
+    const float4 gr = make_float4(dr.x * r.x * (1.f - r.x), dr.y * r.y * (1.f - r.y), dr.z * r.z * (1.f - r.z),
+                                  dr.w * r.w * (1.f - r.w));
+    const int pos = (lr * 16 + (sq ^ (lr & 15))) * 4;
+    *reinterpret_cast<float4*>(&As[pos]) = gz;             // rows past the batch: garbage in, discarded out (row-local)
+    *reinterpret_cast<float4*>(&As[4096 + pos]) = gr;
+    if (ok) {
+      st4b(a.dh, ob, f4_add(dh, f4_mul(dzh, z)));
+      st4b(a.dpg, 2 * (ob - sq * 16) + sq * 16, gz);
+      st4b(a.dpg, 2 * (ob - sq * 16) + 256 + sq * 16, gr);
+    }
+  }
+  __syncthreads();
+  const int passes = (nCt + 7) >> 3;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int ct = w + 8 * pass;
+    // what the block already holds for this pass' rows (the x-column gradient of the layer above): in flight under the MFMAs
+    float4 old[4];
+    if constexpr (BETA) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 512 * q, sl = idx >> 10, lb = (idx >> 4) & 63, s4 = idx & 15;
+        const unsigned slot = (unsigned)min(2 * pass + sl, p.S - 1), b = (unsigned)min(rowBase + lb, p.rows - 1);
+        old[q] = ld4b(p.dA, (((b * p.S + slot) * p.Np + n) * 64 + 4 * s4) * 4u);
+      }
+    }
+    if (ct < nCt) {                             // wave-uniform
+      f32x4 acc[4];
+      const int nextCt = min(ct + 8, nCt - 1);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float* buf = As + (g >> 2) * 4096;
+        float4 av[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          av[rt] = *reinterpret_cast<const float4*>(&buf[((rt * 16 + j) * 16 + ((4 * (g & 3) + kq) ^ j)) * 4]);
+        const float4 wg = wt[g];
+        wt[g] = wload1(nextCt, g);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].x, wg.x, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].y, wg.y, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].z, wg.z, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = MFMA16(av[rt].w, wg.w, acc[rt]);
+        __builtin_amdgcn_sched_barrier(0);        // keeps the A reads of later groups from being hoisted (they spilled)
+      }
+      float* tileOut = Out + (w >> 2) * 4096;
+      const int col = (w & 3) * 16 + j;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tileOut[swz(rt * 16 + 4 * kq + e, col, 16)] = acc[rt][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 512 * q, sl = idx >> 10, lb = (idx >> 4) & 63, s4 = idx & 15;
+      const int slot = 2 * pass + sl, b = rowBase + lb;
+      if (slot < p.S && b < p.rows) {
+        float4 v = *reinterpret_cast<const float4*>(&Out[sl * 4096 + (lb * 16 + (s4 ^ (lb & 15))) * 4]);
+        if constexpr (BETA) v = f4_add(v, old[q]);
+        st4b(p.dA, ((((unsigned)b * p.S + slot) * p.Np + n) * 64 + 4 * s4) * 4u, v);
+      }
+    }
+    if (pass + 1 < passes) __syncthreads();
   }
 }
 

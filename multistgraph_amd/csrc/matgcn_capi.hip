@@ -176,6 +176,10 @@ struct TrainPlan {
   long oGH[MATGCN_MAX_LAYERS], oGZH[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS];
   long keepFloats;                         // [keepFloats, floats) is zeroed by backward
   long oWp[MATGCN_MAX_LAYERS][2], oDWp[MATGCN_MAX_LAYERS][2], oDBias[MATGCN_MAX_LAYERS][2];
+  long oZeroSlab;                          // [B][Np][64] zeros: h_{-1} of a layer without a caller-supplied state (the chain
+                                           // kernels read h_{t-1} unconditionally)
+  long oRUf[MATGCN_MAX_LAYERS], oRGf[MATGCN_MAX_LAYERS];   // fragment-ordered transposes of the residual nn.Linear weights' hidden
+                                                           // columns (B operands of k_chain_res_node; parameter-only)
   // per-layer scratch exists twice (index l & 1): the weight gradients of layer l run on a second stream while the
   // chain of layer l-1 already fills the other set
   long oDPU[2], oDPG[2], oDPU2[2], oDPG2[2];   // pre-activation gradients of every step
@@ -219,6 +223,8 @@ int make_train_plan(const Plan& P, TrainPlan* R) {
       R->oDWp[l][part] = take((long)P.N * R->S * I * O);
       R->oDBias[l][part] = take((long)P.N * O);
     }
+  for (int l = 0; l < P.L; ++l) { R->oRUf[l] = take(4 * 4 * 64 * 4); R->oRGf[l] = take(8 * 4 * 64 * 4); }
+  R->oZeroSlab = take(slab);
   for (int q = 0; q < (P.L > 1 ? 2 : 1); ++q) {
     R->oDPU[q] = take(seq); R->oDPG[q] = take(2 * seq); R->oDPU2[q] = take(seq); R->oDPG2[q] = take(2 * seq);
     R->oDAg[q] = take(seq * R->S); R->oDAu[q] = take(seq * R->S); R->oDAx[q] = take(seq * R->S);

@@ -473,6 +473,14 @@ def test_full_size_directional_derivative(lib_built):
     # node embeddings of other widths than the default 20 (run_model_parameter.py sweeps embed_dim): 8 and 24 take the
     # 3- and 8-step instantiations of the matrix-core prepare / pool-gradient kernels, 40 the kernels for wide embeddings
     (21, 2, 2, {"embed": 8}), (21, 3, 2, {"embed": 24}), (16, 2, 2, {"embed": 40}),
+    # round 4: the values the reference's embed_dim_node sweep actually runs (run_model_parameter.py:14,
+    # [1, 5, 10, 20, 30, 50]) - 1 / 5 / 10 take k_prep_mfma<3>, 30 the <8> instantiation next to its boundary (32), 50 the
+    # kernels for wide embeddings
+    (21, 2, 2, {"embed": 1}), (21, 2, 2, {"embed": 5}), (19, 3, 2, {"embed": 10}), (21, 2, 2, {"embed": 30}),
+    (16, 2, 2, {"embed": 50}),
+    # temporal-head layouts of the reference's first sweep that have no reference fixture (run_model_parameter.py:6-7):
+    # closeness + trend without a period block, closeness + period without trend, two period heads
+    (21, 2, 2, {"lens": (1, 0, 1)}), (21, 3, 2, {"lens": (1, 1, 0)}), (19, 2, 2, {"lens": (1, 2, 1)}),
 ])
 def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags, lib_built):
     """N a multiple of 16 (no padding rows anywhere), a batch that is not a multiple of the 64-row tile, and 1 / 3 / 4
@@ -486,19 +494,20 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     adjtype, adpadj = flags.get("adjtype", "multi"), flags.get("adpadj", "unidirection")
     od, ext = flags.get("end_dim", 1), flags.get("ext", 1)
     emb = flags.get("embed", 20)
-    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext", "embed")}
+    lens = flags.get("lens", (2, 1, 1))
+    abl = {k: v for k, v in flags.items() if k not in ("cheb_order", "adjtype", "adpadj", "end_dim", "ext", "embed", "lens")}
     cfg = dict(input_window=24, output_window=6, add_time_in_day=ext > 0, add_day_in_week=ext in (8, 13),
                load_dynamic=ext == 13,
                adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, embed_dim_node=emb, embed_dim_adj=20, rnn_units=64,
                num_layers=layers, device=torch.device("cpu"), batch_size=b, start_dim=0, end_dim=od, **abl)
-    df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=ext), output_dim=od, feature_dim=od + ext)
+    df = dict(syn.make_data_feature(n, 3, "DC", ext_dim=ext, lens=lens), output_dim=od, feature_dim=od + ext)
     mats = graph_prep.build_static_supports(df["adj_mx"], df["coordinate"], None, adjtype)
     use_static = adpadj == "none" or adjtype == "multi"
     st = torch.from_numpy(np.stack(mats, 0))
     shapes = syn.param_shapes(n, out_steps=6, feat_in=od + ext, out_dim=od, k_total=syn.k_total_for(adjtype, adpadj, cheb),
-                              layers=layers, embed_dim_node=emb, **abl)
+                              layers=layers, embed_dim_node=emb, len_ts=sum(lens), **abl)
     state_np = syn.closed_form_state(shapes, 3)
-    x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=od + ext)
+    x_np, _ = syn.make_batch_arrays(b, n, 6, 3, feat=od + ext, x_steps=24 * sum(lens))
     if od > 1:   # channels [flow 0 .. flow od-1 | time of day]
         x_np = np.ascontiguousarray(np.concatenate([x_np[..., :1], x_np[..., 2:], x_np[..., 1:2]], -1))
     spec = spec_from_config(cfg, df, n, min(n, 20), st.shape[0] if use_static else 0,
@@ -509,8 +518,8 @@ def test_backward_on_synthetic_shapes_outside_the_golden_set(n, b, layers, flags
     rng = np.random.default_rng(9)
     d_out = rng.standard_normal((b, 6, n, od)).astype(np.float32)
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in state_np.items()}
-    ocfg = dict(adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, num_layers=layers, rnn_units=64, len_closeness=48,
-                len_period=24, len_trend=24, output_window=6, input_window=24, add_time_in_day=ext > 0,
+    ocfg = dict(adjtype=adjtype, adpadj=adpadj, cheb_order=cheb, num_layers=layers, rnn_units=64, len_closeness=24 * lens[0],
+                len_period=24 * lens[1], len_trend=24 * lens[2], output_window=6, input_window=24, add_time_in_day=ext > 0,
                 add_day_in_week=ext in (8, 13), load_dynamic=ext == 13, start_dim=0, end_dim=od, **abl)
     y = orc.forward(torch.tensor(x_np, dtype=torch.float64), p, [m.double() for m in st] if use_static else [], ocfg,
                     faithful=False)
