@@ -117,7 +117,10 @@ typedef struct matgcn_params { /* device pointers, names = the reference state_d
 int matgcn_abi_version(void);
 const char* matgcn_error_string(int status);
 
-/* Bytes of the two caller-owned device buffers for `dims`. */
+/* Bytes of the two caller-owned device buffers for `dims`.  matgcn_workspace_bytes depends on ONE library setting: while
+ * matgcn_set_mix_precision(2) is in force it also counts the bf16 copies of the recurrent weight streams (half the bytes of
+ * the fp32 streams, behind everything else); a mode-2 forward on a workspace sized without them returns
+ * MATGCN_ERR_SMALL_BUFFER (ask again and re-allocate).  The fp32 product path and training never pay for them. */
 int matgcn_prepared_bytes(const matgcn_dims* dims, size_t* bytes);
 int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes);
 

@@ -55,6 +55,7 @@ struct Plan {
   long oHx[MATGCN_MAX_LAYERS], oZHx[MATGCN_MAX_LAYERS], oG[MATGCN_MAX_LAYERS], oR[MATGCN_MAX_LAYERS];
   long oSeq[MATGCN_MAX_LAYERS], oGX[MATGCN_MAX_LAYERS], oPX[MATGCN_MAX_LAYERS];
   long workspaceFloats;
+  long workspaceFloatsBf16;   // with the bf16 weight-stream copies of precision mode 2 behind everything else
 };
 
 int make_plan(const matgcn_dims* D, Plan* P) {
@@ -150,14 +151,20 @@ int make_plan(const matgcn_dims* D, Plan* P) {
     P->oG[l] = take((long)P->N * P->B * P->Ks * H);
     P->oR[l] = take((long)P->N * P->RB * NODE_R_BLOCK);
     P->oSeq[l] = take(rowsBT * P->Np * H);
-    P->oW16g[l] = take((P->wgFloats[l] + 1) / 2);   // bf16: two values per float slot
-    P->oW16u[l] = take((P->wuFloats[l] + 1) / 2);
     if (l > 0 && !P->gcnOff) {
       P->oGX[l] = take((long)P->T * P->N * P->B * P->Ks * H);   // every chunk keeps its own block [N][nt*B][Ks][64]
       P->oPX[l] = take((long)P->T * P->N * P->RB * NODE_PX_BLOCK);
     }
   }
   P->workspaceFloats = o;
+  // optional tail, precision mode 2 only (half the bytes of the fp32 weight streams - +125 MB at N = 403,
+  // several hundred MB at N = 4096 - that the fp32 product path and training never touch): matgcn_workspace_bytes counts
+  // it only while mode 2 is set, and a mode-2 forward on a workspace without it returns MATGCN_ERR_SMALL_BUFFER
+  for (int l = 0; l < P->L; ++l) {
+    P->oW16g[l] = take((P->wgFloats[l] + 1) / 2);   // bf16: two values per float slot
+    P->oW16u[l] = take((P->wuFloats[l] + 1) / 2);
+  }
+  P->workspaceFloatsBf16 = o;
   return MATGCN_OK;
 }
 
@@ -494,6 +501,12 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   if (g_mix_bf16_now) {   // opt-in bf16-operand variant of the inference forward (fp32 accumulate, fp32 in / out)
     if (stepRole) hipLaunchKernelGGL(k_mix_bf16<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_mix_bf16<0>, grid, dim3(256), 0, s, a);
+#ifndef MIX_FLUSH_MIN_NK
+#define MIX_FLUSH_MIN_NK 64
+#endif
+  } else if (a.nK > MIX_FLUSH_MIN_NK) {   // more than 1 024 reduction indices: partial sums every 256 (k_mix's FLUSH)
+    if (stepRole) hipLaunchKernelGGL((k_mix<1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_mix<0, true>), grid, dim3(256), 0, s, a);
   } else if (stepRole) {
     hipLaunchKernelGGL(k_mix<1>, grid, dim3(256), 0, s, a);
   } else {
@@ -540,6 +553,7 @@ struct Ctx {
   const matgcn_params* prm;
   const float* prep;
   float* ws;
+  size_t wsBytes = 0;
   hipStream_t s;
   float* train = nullptr;     // matgcn_forward_train: the training buffer (activations are saved into it)
   TrainPlan R;
@@ -787,6 +801,7 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
   // one stream, the bf16 copies (they read every stream) and the dense-GRU ablation take everything up front
   if (lazyPrep && (!multi || g_node_bf16_now || P.gcnOff)) RETURN_IF(prep_wait(c.s, 3));
   if (g_node_bf16_now && !P.gcnOff && !c.train) {
+    if (c.wsBytes < (size_t)P.workspaceFloatsBf16 * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;   // sized without mode 2
     // precision mode 2: bf16 copies of the recurrent weight streams into the workspace, once per forward and in front
     // of the fork (every chain reads them); 240 MB of traffic, part of what the side line's time includes
     for (int l = 0; l < P.L; ++l) {
@@ -947,6 +962,7 @@ int make_ctx(Ctx* c, const matgcn_dims* dims, const matgcn_params* params, const
   RETURN_IF(make_plan(dims, &c->P));
   if (workspace_bytes < (size_t)c->P.workspaceFloats * sizeof(float)) return MATGCN_ERR_SMALL_BUFFER;
   c->D = dims; c->prm = params; c->prep = (const float*)prepared; c->ws = (float*)workspace;
+  c->wsBytes = workspace_bytes;
   c->s = (hipStream_t)stream;
   if (prepared && joinPrepare) RETURN_IF(prep_wait(c->s, 3));
   return MATGCN_OK;
@@ -1123,7 +1139,7 @@ int matgcn_workspace_bytes(const matgcn_dims* dims, size_t* bytes) {
   if (!bytes) return MATGCN_ERR_NULL;
   Plan P;
   RETURN_IF(make_plan(dims, &P));
-  size_t need = (size_t)P.workspaceFloats * sizeof(float);
+  size_t need = (size_t)(g_mix_precision == 2 ? P.workspaceFloatsBf16 : P.workspaceFloats) * sizeof(float);
   if (dims->batch >= 2 && !(dims->batch & 1)) {     // room for the two half-batch plans of the batch-split forward
     matgcn_dims half = *dims;
     half.batch = dims->batch / 2;
@@ -1155,8 +1171,17 @@ int matgcn_weights_layout(const matgcn_dims* dims, int layer, int part, int64_t 
   return MATGCN_OK;
 }
 
+static int prepare_impl(const matgcn_dims* dims, const matgcn_params* params, void* prepared, size_t prepared_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream);
+// (a failure between the fork onto the library streams and their join - eager or lazy - joins them into the caller's
+// stream before the error code is returned, like every other forking entry point: the caller may free or reuse
+// `prepared` as soon as its own stream is idle)
 int matgcn_prepare(const matgcn_dims* dims, const matgcn_params* params, void* prepared, size_t prepared_bytes,
                    void* workspace, size_t workspace_bytes, void* stream) {
+  JOINED(prepare_impl(dims, params, prepared, prepared_bytes, workspace, workspace_bytes, stream), stream);
+}
+static int prepare_impl(const matgcn_dims* dims, const matgcn_params* params, void* prepared, size_t prepared_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream));

@@ -601,8 +601,18 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // XCD (id % 8) sweep the row tiles of one column tile back to back, so St and that X slice stay in its L2.
 // ROLE only names the instantiation (0: pre-passes and Chebyshev products, 1: the recurrent step's mix of h / z*h),
 // so that profilers list the roofline kernel - the per-step launch - on its own line.
-template <int ROLE>
+// FLUSH (round 4): the accumulators are one fp32 fma chain over the WHOLE reduction - 4 096 links at N = 4 096, where the
+// reference's own prediction sits 4.7e-7 from its float64 run and this kernel's single chain left the path at 1.2e-6
+// (tests/golden/fp64_gap.npz; a blocked CPU sgemm sums K in blocks of a few hundred).  With FLUSH the chain is cut every
+// MIX_FLUSH_TILES K-tiles (256 reduction indices): partial sums go to a second accumulator set.  Launched for nK > 64 only,
+// so every graph of at most 1 024 nodes - the headline's 403 - keeps its kernel and its bits.
+#ifndef MIX_FLUSH_TILES
+#define MIX_FLUSH_TILES 16
+#endif
+template <int ROLE, bool FLUSH = false>
 __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
+  // (FLUSH costs 16 registers, 72 in all: seven workgroups per CU instead of eight, +3.7 % per launch at N = 4 096; forced
+  //  into 64 registers the compiler spilled a pointer inside the K loop, +6.5 %: profiles/r04_mix_lab.log)
   __shared__ __attribute__((aligned(16))) float As[2][16 * 64];
   __shared__ __attribute__((aligned(16))) float Bs[2][16 * 64];
   const int id = blockIdx.x;
@@ -634,20 +644,33 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int last = a.nK - 1;
   auto ldA = [&](int t) { return *reinterpret_cast<const float4*>(ap + (size_t)min(t, last) * 16 * a.ldS); };
   auto ldB = [&](int t) { return *reinterpret_cast<const float4*>(bp + (size_t)min(t, last) * 16 * a.ldX); };
+  // All six requests of the prologue leave BEFORE the first wait (round 4: at 48 registers the compiler had serialised
+  // them to save two - load A0, wait, store, load B0, wait, store, and only then tiles 1 and 2: two exposed memory round
+  // trips in front of every launch's first MFMA; the sched_barrier pins the order, the stores then wait with vmcnt(5) / (4))
+  float4 ra0, rb0, ra1, rb1;
   {
     const float4 a0 = ldA(0), b0 = ldB(0);
+#ifndef MIX_LAB_SERIAL_PROLOGUE
+    __builtin_amdgcn_sched_barrier(0);    // tile 0 first: its stores wait for the two OLDEST requests only
+#endif
+    ra0 = ldA(1); rb0 = ldB(1); ra1 = ldA(2); rb1 = ldB(2);
+#ifndef MIX_LAB_SERIAL_PROLOGUE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     *reinterpret_cast<float4*>(&As[0][stPos]) = a0;
     *reinterpret_cast<float4*>(&Bs[0][stPos]) = b0;
   }
-  float4 ra0 = ldA(1), rb0 = ldB(1), ra1 = ldA(2), rb1 = ldB(2);
   __syncthreads();
   // the wave's 32x32 output tile = 2x2 accumulators of v_mfma_f32_16x16x4_f32: 20 independent accumulator chains
   // per SIMD at 5 resident workgroups per CU, enough to keep the matrix pipe issuing back to back
-  f32x4 acc[2][2];
+  f32x4 acc[2][2], tot[FLUSH ? 2 : 1][2];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 2; ++q) {
+      acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FLUSH) tot[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   const int rotA0 = (wr * 32 + j + 16 * kq) & 63, rotA1 = (wr * 32 + 16 + j + 16 * kq) & 63;
   const int rotB0 = (wc * 32 + j + 16 * kq) & 63, rotB1 = (wc * 32 + 16 + j + 16 * kq) & 63;
   auto mma = [&](int cur) {
@@ -681,6 +704,26 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
       ra1 = ldA(it + 4); rb1 = ldB(it + 4);
       __syncthreads();
     }
+    if constexpr (FLUSH) {
+      if (((it + 2) & (MIX_FLUSH_TILES - 1)) == 0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[p][q][e] += acc[p][q][e];
+            acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+    }
+  }
+  if constexpr (FLUSH) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[p][q][e] += tot[p][q][e];
   }
   // Epilogue: each wave turns its 32x32 accumulator tile through LDS (the K-loop buffers are free after the last
   // barrier; 16-byte slots XOR-swizzled by row so both the scalar writes and the b128 reads are conflict-free)
@@ -763,13 +806,20 @@ __global__ __launch_bounds__(256) void k_mix_n32(MixArgs a) {
   auto ldA = [&](int t) { return *reinterpret_cast<const float4*>(ap + (size_t)min(t, last) * 16 * a.ldS); };
   auto ldB0 = [&](int t) { return *reinterpret_cast<const float4*>(bp0 + (size_t)min(t, last) * 16 * a.ldX); };
   auto ldB1 = [&](int t) { return *reinterpret_cast<const float4*>(bp1 + (size_t)min(t, last) * 16 * a.ldX); };
+  float4 ra0, rb00, rb01, ra1, rb10, rb11;   // (every request of the prologue before its first wait: see k_mix)
   {
     const float4 a0 = ldA(0), b0 = ldB0(0), b1 = ldB1(0);
+#ifndef MIX_LAB_SERIAL_PROLOGUE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    ra0 = ldA(1); rb00 = ldB0(1); rb01 = ldB1(1); ra1 = ldA(2); rb10 = ldB0(2); rb11 = ldB1(2);
+#ifndef MIX_LAB_SERIAL_PROLOGUE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     *reinterpret_cast<float4*>(&As[0][aPos]) = a0;
     *reinterpret_cast<float4*>(&Bs[0][bPos0]) = b0;
     *reinterpret_cast<float4*>(&Bs[0][bPos1]) = b1;
   }
-  float4 ra0 = ldA(1), rb00 = ldB0(1), rb01 = ldB1(1), ra1 = ldA(2), rb10 = ldB0(2), rb11 = ldB1(2);
   __syncthreads();
   f32x4 acc[2][2];
 #pragma unroll

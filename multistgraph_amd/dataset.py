@@ -149,6 +149,8 @@ class ResidentBatch:
     def __setitem__(self, key, value):
         if key in self:
             self.data[key] = value
+            if key in ("label_start", "series", "rel_steps"):   # no longer what the owner validated on the host
+                self.range_checked = False
         else:
             raise KeyError("{} is not in the batch".format(key))
 

@@ -235,7 +235,7 @@ class MultiATGCN(AbstractTrafficStateModel):
         if self.node_specific_off:  # (:350-354)
             self.node_emb = nn.Parameter(torch.ones(n, 1), requires_grad=False)
         self._paths: Dict[int, HotPath] = {}
-        self._valid_label_tables = set()
+        self._valid_label_tables = {}
         self._prepared_key = None
         self.cache_prepared = True
 
@@ -360,29 +360,45 @@ class MultiATGCN(AbstractTrafficStateModel):
         ls = label_start.to(torch.int32)
         if trusted:
             return (series, ls, rel_steps)
-        base = ls._base if ls._base is not None else ls      # a row of a validated table is a view of it
-        key = (base.data_ptr(), base._version, steps, tuple(int(v) for v in (min(rel_steps), max(rel_steps))))
-        if key not in self._valid_label_tables:
-            lo, hi = (int(v) for v in torch.aminmax(ls))
-            windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
-            if len(self._valid_label_tables) > 64:
-                self._valid_label_tables.clear()
-            if base is not ls:
-                lo, hi = (int(v) for v in torch.aminmax(base))
-                try:
-                    windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
-                    self._valid_label_tables.add(key)      # the whole table holds: its other rows need no check
-                except ValueError:
-                    pass
-            else:
-                self._valid_label_tables.add(key)
+        # Only tables that were registered as OBJECTS are trusted (a key built from data_ptr() survives
+        # the tensor - the caching allocator hands the same address to the next batch, whose _version is 0 again - so a
+        # later out-of-range batch could hit the stale key and skip the check).  A row of a registered table is a view of
+        # it (``_base``); anything else - a fresh tensor per batch, the int32 copy of an int64 tensor - is checked on every
+        # call (one min / max read-back).
+        base = ls._base if ls._base is not None else ls
+        rel_key = tuple(int(v) for v in (min(rel_steps), max(rel_steps)))
+        if self._label_table_is_valid(base, steps, rel_key):
+            return (series, ls, rel_steps)
+        lo, hi = (int(v) for v in torch.aminmax(ls))
+        windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
+        if base is not ls:      # a view of a longer-lived table: validate the table once, then trust its other rows
+            lo, hi = (int(v) for v in torch.aminmax(base))
+            try:
+                windows.check_label_starts(np.array([lo, hi]), rel_steps, self.output_window, steps)
+                self.mark_label_starts_valid(base, steps, rel_steps)
+            except ValueError:
+                pass
         return (series, ls, rel_steps)
+
+    def _label_table_is_valid(self, table: torch.Tensor, steps: int, rel_key) -> bool:
+        ent = self._valid_label_tables.get(id(table))
+        if ent is None:
+            return False
+        ref, version, st, rk = ent
+        if ref() is not table:      # the id belongs to a dead tensor: forget it
+            del self._valid_label_tables[id(table)]
+            return False
+        return version == table._version and st == steps and rk == rel_key
 
     def mark_label_starts_valid(self, table: torch.Tensor, series_steps: int, rel_steps) -> None:
         """Register a device table of label starts that has been validated on the host (windows.check_label_starts):
-        batches that are views of it skip the per-call range check."""
-        self._valid_label_tables.add((table.data_ptr(), table._version, int(series_steps),
-                                      tuple(int(v) for v in (min(rel_steps), max(rel_steps)))))
+        batches that are views of it skip the per-call range check.  The table is remembered as an object (weak
+        reference + ``_version``): writing into it, or its death, ends the trust."""
+        import weakref
+        if len(self._valid_label_tables) > 64:
+            self._valid_label_tables = {k: v for k, v in self._valid_label_tables.items() if v[0]() is not None}
+        self._valid_label_tables[id(table)] = (weakref.ref(table), table._version, int(series_steps),
+                                               tuple(int(v) for v in (min(rel_steps), max(rel_steps))))
 
     def forward_series(self, series: torch.Tensor, label_start: torch.Tensor, rel_steps=None):
         """forward() without materialised windows: ``series`` (T, N, F) float32 resident on the GPU, ``label_start``

@@ -324,6 +324,21 @@ class HotPath:
         self.train_generation += 1
         return C.c_void_p(self.workspace.data_ptr()), C.c_size_t(self.workspace.numel() * 4)
 
+    def _with_workspace(self, call, what: str) -> None:
+        """Run ``call(ws_ptr, ws_bytes)``; a workspace that is too small for the CURRENT library mode - precision mode 2
+        was switched on after this binding sized it: the bf16 weight-stream copies are counted only while that mode is
+        set - is re-sized once and the call repeated."""
+        ws, wsb = self._ws()
+        status = call(ws, wsb)
+        if status == -4:      # MATGCN_ERR_SMALL_BUFFER
+            nbytes = C.c_size_t()
+            _lib.check(self.lib.matgcn_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "matgcn_workspace_bytes")
+            if nbytes.value > self.workspace.numel() * 4:
+                self.workspace = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+                ws, wsb = self._ws()
+                status = call(ws, wsb)
+        _lib.check(status, what)
+
     def bind(self, state: Dict[str, torch.Tensor], static_supports: Optional[torch.Tensor]):
         """Point matgcn_params at the tensors of a reference-named state dict."""
         s, p = self.spec, self.params
@@ -392,12 +407,23 @@ class HotPath:
         _lib.check(self.lib.matgcn_prepare_join(self._stream()), "matgcn_prepare_join")
 
     def __del__(self):
-        # `prepared` goes back to torch's allocator when this object dies: nothing of the library may still write it
+        # `prepared` goes back to torch's allocator when this object dies: nothing of the library may still write it.
+        # The lazy prepare's events live per DEVICE (the library picks them by hipGetDevice()), and the allocator reuses
+        # the block in order of the stream it was allocated on: join on this binding's device and on that stream, and
+        # additionally tell the allocator about the joining stream when it is another one (a join issued
+        # under another current device / stream context landed on the wrong ones).
         try:
             if self._prepared_ok and torch.cuda.is_available():
-                self.lib.matgcn_prepare_join(self._stream())
-        except Exception:
-            pass
+                with torch.cuda.device(self.device):
+                    cur = torch.cuda.current_stream(self.device)
+                    self.lib.matgcn_prepare_join(C.c_void_p(cur.cuda_stream))
+                    self.prepared.record_stream(cur)
+        except Exception as exc:   # interpreter shutdown: torch may already be gone - say so instead of hiding it
+            try:
+                import warnings
+                warnings.warn("HotPath.__del__: matgcn_prepare_join failed (%r)" % (exc,), RuntimeWarning)
+            except Exception:
+                pass
 
     def _source(self, x):
         """The batch of a training step: a windows tensor X (B, x_steps, N, F), or a (series, label_start, rel_steps)
@@ -434,11 +460,9 @@ class HotPath:
         h0 = self._h0(h0)
         self._need_prepared()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
-        ws, wsb = self._ws()
-        _lib.check(self.lib.matgcn_forward(C.byref(self.dims), C.byref(self.params),
-                                           C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
-                                           C.c_void_p(_ptr(h0)), C.c_void_p(out.data_ptr()), ws, wsb, self._stream()),
-                   "matgcn_forward")
+        self._with_workspace(lambda ws, wsb: self.lib.matgcn_forward(
+            C.byref(self.dims), C.byref(self.params), C.c_void_p(self.prepared.data_ptr()), C.c_void_p(x.data_ptr()),
+            C.c_void_p(_ptr(h0)), C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward")
         return out
 
     # ---- training step ---------------------------------------------------
@@ -575,9 +599,8 @@ class HotPath:
         h0 = self._h0(h0)
         self._need_prepared()
         out = torch.empty(self.batch, s.out_window, s.nodes, s.out_dim, dtype=torch.float32, device=self.device)
-        ws, wsb = self._ws()
         rel_c = (C.c_int32 * len(rel))(*rel)
-        _lib.check(self.lib.matgcn_forward_series(
+        self._with_workspace(lambda ws, wsb: self.lib.matgcn_forward_series(
             C.byref(self.dims), C.byref(self.params), C.c_void_p(self.prepared.data_ptr()),
             C.c_void_p(series.data_ptr()), C.c_int64(series.shape[0]), C.c_void_p(label_start.contiguous().data_ptr()),
             rel_c, C.c_void_p(_ptr(h0)), C.c_void_p(out.data_ptr()), ws, wsb, self._stream()), "matgcn_forward_series")

@@ -103,8 +103,15 @@ def allreduce_model_grads_(model, group=None, check: bool = True) -> dict:
         bucket, rest = None, [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
     layout = [0 if bucket is None else 1, 0 if bucket is None else bucket.numel(), sum(t.numel() for t in rest)]
     if check:
-        some = bucket if bucket is not None else (rest[0] if rest else None)
-        dev = some.device if some is not None and dist.get_backend(group) == "nccl" else None
+        # where the layout vote travels: under nccl / RCCL every rank needs a GPU tensor - also a rank that has no
+        # gradient at all (it used to build a CPU tensor, raise alone and leave its peers in the
+        # collective): take the device from the gradients, else from the parameters, else the current device
+        dev = None
+        if dist.get_backend(group) == "nccl":
+            some = bucket if bucket is not None else (rest[0] if rest else None)
+            if some is None:
+                some = next((p for p in model.parameters() if p.is_cuda), None) if hasattr(model, "parameters") else None
+            dev = some.device if some is not None and some.is_cuda else torch.device("cuda", torch.cuda.current_device())
         lo = torch.tensor(layout, dtype=torch.int64, device=dev)
         both = torch.stack([lo, -lo])                 # one MIN gives the minimum and (negated) the maximum
         dist.all_reduce(both, op=dist.ReduceOp.MIN, group=group)
