@@ -486,6 +486,24 @@ void join_one_set(Wavefront& W, hipStream_t caller) {
     return rc_;                                                           \
   } while (0)
 
+#ifdef NODE_LAB_STAMPS   // lab builds only (tools/labs/stamps_r04.py): where the node kernels' in-kernel stamps go
+unsigned int* g_lab_stamps = nullptr;
+size_t g_lab_stamp_words = 0;
+int g_lab_stamp_launch = 0;
+int g_lab_stamp_kinds = 1;   // 1: node kernels (k_gate16 / k_update16), 2: k_mix<1>
+extern "C" int matgcn_lab_stamps(void* buf, size_t words) {
+  g_lab_stamps = static_cast<unsigned int*>(buf); g_lab_stamp_words = words; g_lab_stamp_launch = 0;
+  return MATGCN_OK;
+}
+extern "C" int matgcn_lab_stamp_launches(void) { return g_lab_stamp_launch; }
+extern "C" int matgcn_lab_stamp_kinds(int kinds) { g_lab_stamp_kinds = kinds; return MATGCN_OK; }
+static unsigned int* lab_stamp_slot(unsigned gridBlocks, int wavesPerBlock = 8) {
+  const size_t per = (size_t)gridBlocks * wavesPerBlock * NODE_STAMPS;
+  if (!g_lab_stamps || (size_t)(g_lab_stamp_launch + 1) * per > g_lab_stamp_words) return nullptr;
+  return g_lab_stamps + (size_t)(g_lab_stamp_launch++) * per;
+}
+#endif
+
 // out[(k,n)][col] = sum_m S_k[n][m] X[m][col]; see k_mix
 int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride, int ldX, int nColTiles,
                float* out, long sN, long sK, long sT, int Ks, int rowsM, hipStream_t s, bool stepRole = false,
@@ -498,6 +516,9 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   a.nRowTiles = (int)(rup(rowsM, 64) / 64);
   ProfScope prof(stepRole ? MATGCN_PROF_MIX : MATGCN_PROF_MIX_PRE, s);
   const dim3 grid((unsigned)(a.nRowTiles * nColTiles));
+#ifdef NODE_LAB_STAMPS
+  if (stepRole && (g_lab_stamp_kinds & 2)) a.stamps = lab_stamp_slot(grid.x, 4);
+#endif
   if (g_mix_bf16_now) {   // opt-in bf16-operand variant of the inference forward (fp32 accumulate, fp32 in / out)
     if (stepRole) hipLaunchKernelGGL(k_mix_bf16<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_mix_bf16<0>, grid, dim3(256), 0, s, a);
@@ -667,21 +688,6 @@ void fill_res_args(const Ctx& c, int l, const float* xt, long xRowStride, const 
   a->blend = blend; a->seq = seq_t; a->seqRowStride = (long)P.Np * H;
 }
 
-#ifdef NODE_LAB_STAMPS   // lab builds only (tools/labs/stamps_r04.py): where the node kernels' in-kernel stamps go
-unsigned int* g_lab_stamps = nullptr;
-size_t g_lab_stamp_words = 0;
-int g_lab_stamp_launch = 0;
-extern "C" int matgcn_lab_stamps(void* buf, size_t words) {
-  g_lab_stamps = static_cast<unsigned int*>(buf); g_lab_stamp_words = words; g_lab_stamp_launch = 0;
-  return MATGCN_OK;
-}
-extern "C" int matgcn_lab_stamp_launches(void) { return g_lab_stamp_launch; }
-static unsigned int* lab_stamp_slot(unsigned gridBlocks) {
-  const size_t per = (size_t)gridBlocks * 8 * NODE_STAMPS;
-  if (!g_lab_stamps || (size_t)(g_lab_stamp_launch + 1) * per > g_lab_stamp_words) return nullptr;
-  return g_lab_stamps + (size_t)(g_lab_stamp_launch++) * per;
-}
-#endif
 
 // phase 0: mix(h) -> G;  1: gate;  2: mix(z*h) -> G;  3: update [+ residual cell + blend when `res` is set]
 int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Args* res, hipStream_t s) {
@@ -713,7 +719,7 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   const bool rows32 = NODE_ROWS == 64 && P.B <= 32 && !save && res != nullptr && !raw && !g_node_bf16_now;
   const dim3 grid(node_items(P.N, P.B, rows32 ? 32 : NODE_ROWS));   // (node, row block) work items, XCD-paired per node
 #ifdef NODE_LAB_STAMPS
-  a.stamps = lab_stamp_slot(grid.x);
+  a.stamps = (g_lab_stamp_kinds & 1) ? lab_stamp_slot(grid.x) : nullptr;
 #endif
   if (save) {
     const size_t at = (size_t)t * P.B * P.Np * H;

@@ -83,6 +83,9 @@ struct MixArgs {
   // of X and writes its own partial result - the transposed mix of the backward splits by support slot
   int parts = 1;
   long aPartStride = 0, xPartStride = 0, outPartStride = 0;
+#ifdef NODE_LAB_STAMPS
+  unsigned int* stamps = nullptr;   // lab builds: per-wave phase stamps of this launch
+#endif
 };
 
 struct HeadArgs {
@@ -92,5 +95,39 @@ struct HeadArgs {
   float* out;
   int B, T, N, Np, CH, od, NTc;   // seq is time-major [T][B][Np][64]
 };
+
+// ---- lab only: in-kernel phase stamps (s_memtime at wave granularity, kept in SGPRs, written once at the end) ----
+#ifdef NODE_LAB_STAMPS
+#define NODE_STAMPS 28
+struct NodeStamps {
+  unsigned int t[NODE_STAMPS];
+  __device__ __forceinline__ void at(int i) {
+    t[i] = (unsigned int)__builtin_amdgcn_s_memtime();
+    if (i == 0) t[24] = (unsigned int)__builtin_amdgcn_s_memrealtime();
+  }
+  __device__ __forceinline__ void flush(unsigned int* out) {
+    if (!out) return;
+    t[25] = (unsigned int)__builtin_amdgcn_s_memrealtime();
+    t[26] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+    t[27] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+    if ((threadIdx.x & 63) == 0) {
+      unsigned int* o = out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NODE_STAMPS;
+#pragma unroll
+      for (int i = 0; i < NODE_STAMPS; ++i) o[i] = t[i];
+    }
+  }
+};
+#define NODE_STAMP_DECL NodeStamps nst; for (int i_ = 0; i_ < NODE_STAMPS; ++i_) nst.t[i_] = 0;
+#define NODE_STAMP(i) nst.at(i)
+#define NODE_STAMP_ARG , nst
+#define NODE_STAMP_PARAM , NodeStamps& nst
+#define NODE_STAMP_FLUSH(a) nst.flush((a).stamps)
+#else
+#define NODE_STAMP_DECL
+#define NODE_STAMP(i)
+#define NODE_STAMP_ARG
+#define NODE_STAMP_PARAM
+#define NODE_STAMP_FLUSH(a)
+#endif
 
 #endif

@@ -606,6 +606,12 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // (tests/golden/fp64_gap.npz; a blocked CPU sgemm sums K in blocks of a few hundred).  With FLUSH the chain is cut every
 // MIX_FLUSH_TILES K-tiles (256 reduction indices): partial sums go to a second accumulator set.  Launched for nK > 64 only,
 // so every graph of at most 1 024 nodes - the headline's 403 - keeps its kernel and its bits.
+#ifndef MIX_PRIO_ROTATE
+#define MIX_PRIO_ROTATE 0
+#endif
+#ifndef MIX_PRIO_SHIFT
+#define MIX_PRIO_SHIFT 1      // the priority moves on every 2^MIX_PRIO_SHIFT K-tiles
+#endif
 #ifndef MIX_FLUSH_TILES
 #define MIX_FLUSH_TILES 16
 #endif
@@ -633,6 +639,8 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   for (int d = 0; d < (int)(blockIdx.x >> 8); ++d) __builtin_amdgcn_s_sleep(MIX_LAB_STAGGER);
 #endif
   const int part = blockIdx.y;     // split reduction (MixArgs.parts): 0 unless the launch has a second grid dimension
+  NODE_STAMP_DECL
+  NODE_STAMP(0);
   const float* ap = a.St + (size_t)part * a.aPartStride + (size_t)kk * a.ldS + row0 + sg * 4;
   const float* bp = a.X + (size_t)part * a.xPartStride + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + sg * 4;
   // LDS image of a K-tile: row kk (one reduction index, 64 values) rotated by 16*(kk&3) floats, so that the four
@@ -657,10 +665,14 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
 #ifndef MIX_LAB_SERIAL_PROLOGUE
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    NODE_STAMP(1);   // six requests issued
     *reinterpret_cast<float4*>(&As[0][stPos]) = a0;
+    NODE_STAMP(2);   // A tile 0 arrived
     *reinterpret_cast<float4*>(&Bs[0][stPos]) = b0;
+    NODE_STAMP(3);   // B tile 0 arrived
   }
   __syncthreads();
+  NODE_STAMP(4);
   // the wave's 32x32 output tile = 2x2 accumulators of v_mfma_f32_16x16x4_f32: 20 independent accumulator chains
   // per SIMD at 5 resident workgroups per CU, enough to keep the matrix pipe issuing back to back
   f32x4 acc[2][2], tot[FLUSH ? 2 : 1][2];
@@ -692,6 +704,19 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int nKrun = a.nK;
 #endif
   for (int it = 0; it < nKrun; it += 2) {
+#if MIX_PRIO_ROTATE
+    // The five workgroups of a CU share each SIMD's matrix pipe, and the arbiter prefers the OLDEST wave: in-kernel stamps
+    // (round 4, tools/labs/stamps_mix_r04.py) show the workgroups of one CU leaving one after the other between 58 k and
+    // 85 k cycles for 66.5 k cycles of MFMA work - the last ones alone on their SIMD, where a single wave cannot keep the
+    // pipe busy.  Priority outranks age: rotating it with the K-tile index by the workgroup's dispatch round (ids 256 apart
+    // share a CU) hands the top priority round, so the five progress together and leave together.
+    switch (((it >> MIX_PRIO_SHIFT) + (int)(blockIdx.x >> 8)) & 3) {   // (s_setprio takes an immediate)
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     mma(0);                                               // tile it
     *reinterpret_cast<float4*>(&As[1][stPos]) = ra0;      // tile it+1 (a clamped copy past the end: unused)
     *reinterpret_cast<float4*>(&Bs[1][stPos]) = rb0;
@@ -730,39 +755,62 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   // and writes whole 128-byte row segments with 16-byte WRITE-THROUGH stores (sc1): the 20-75 MB this kernel
   // produces then leave the L2 while it is still computing instead of as one dirty-line flush at its end, which
   // the next kernel of the chain would otherwise wait for.
+  NODE_STAMP(5);   // K loop issued
+  // (round 4: the last workgroup of a CU runs this stretch alone, one wave per SIMD - 8.5 k cycles by the stamps of
+  //  tools/labs/stamps_mix_r04.py: sixteen scalar LDS writes with seven address instructions each, then four times read ->
+  //  wait -> 64-bit divide -> guarded store.  Now the sixteen offsets are three adds from precomputed pieces, the four
+  //  rows are read in one batch, and a row outside the output is dropped by the buffer's range check instead of a branch.)
   float* stg = (w < 2 ? &As[0][0] : &Bs[0][0]) + (w & 1) * 1024;
+  {
+    const int jq = j >> 2, jr = j & 3, kb = kq & 1;
+    int xe[4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+    for (int e = 0; e < 4; ++e) xe[e] = e * 32 + ((jq ^ e) << 2) + jr;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int lrow = p * 16 + 4 * kq + e, lcol = q * 16 + j;
-        stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
+      for (int q = 0; q < 2; ++q) {
+        const int base = (p * 16 + 4 * kq) * 32 + ((q ^ kb) << 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stg[base + xe[e]] = acc[p][q][e];
       }
+  }
+  NODE_STAMP(6);   // accumulators -> LDS
   const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
   float* outp = a.out + (size_t)part * a.outPartStride;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+  float4 v4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int lrow = u * 8 + (lane >> 3), q = lane & 7;
-    const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+    v4[u] = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lrow = u * 8 + (lane >> 3), q = lane & 7;
+    const float4 v = v4[u];
     const int row = row0 + wr * 32 + lrow;
     const int k = row / a.Np, n = row - k * a.Np;
 #ifdef MIX_LAB_NOSTORE   // LAB: no output (a never-true condition keeps the accumulators alive)
-    if (k < a.Ks && n < a.N && v.x == 1.2345e-30f) {
+    const bool ok = k < a.Ks && n < a.N && v.x == 1.2345e-30f;
 #else
-    if (k < a.Ks && n < a.N) {
+    const bool ok = k < a.Ks && n < a.N;
 #endif
-      const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
-      if (wt) {
-        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
-      } else {
-        *reinterpret_cast<float4*>(outp + off) = v;
-      }
+    const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
+    if (wt) {
+      const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      // a row outside the output: an offset beyond num_records - the store is dropped by the range check, no branch
+      __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, ok ? (int)(off * 4) : (int)0x7ffffff0, 0, 16);   // aux 16 = sc1
+    } else if (ok) {
+      *reinterpret_cast<float4*>(outp + off) = v;
     }
   }
+  NODE_STAMP(7);   // stores issued
+#ifdef NODE_LAB_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  NODE_STAMP(8);   // stores acknowledged
+#endif
+  NODE_STAMP_FLUSH(a);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -859,35 +907,46 @@ __global__ __launch_bounds__(256) void k_mix_n32(MixArgs a) {
       __syncthreads();
     }
   }
-  // epilogue as k_mix: the wave's 32 x 32 tile through LDS (Bs is free after the last barrier), 16-byte write-through stores
+  // epilogue as k_mix (batched, branch-free: round 4): the wave's 32 x 32 tile through LDS (Bs is free after the last
+  // barrier), 16-byte write-through stores
   float* stg = &Bs[0][0] + w * 1024;
+  {
+    const int jq = j >> 2, jr = j & 3, kb = kq & 1;
+    int xe[4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+    for (int e = 0; e < 4; ++e) xe[e] = e * 32 + ((jq ^ e) << 2) + jr;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int lrow = p * 16 + 4 * kq + e, lcol = q * 16 + j;
-        stg[lrow * 32 + (((lcol >> 2) ^ (lrow & 7)) << 2) + (lcol & 3)] = acc[p][q][e];
+      for (int q = 0; q < 2; ++q) {
+        const int base = (p * 16 + 4 * kq) * 32 + ((q ^ kb) << 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stg[base + xe[e]] = acc[p][q][e];
       }
+  }
   const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);   // 32-bit byte offsets
   float* outp = a.out + (size_t)part * a.outPartStride;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
   const int colTile = 2 * colPair + (w >> 1), wc = w & 1;
+  float4 v4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int lrow = u * 8 + (lane >> 3), q = lane & 7;
-    const float4 v = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+    v4[u] = *reinterpret_cast<const float4*>(&stg[lrow * 32 + ((q ^ (lrow & 7)) << 2)]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lrow = u * 8 + (lane >> 3), q = lane & 7;
+    const float4 v = v4[u];
     const int row = row0 + lrow;
     const int k = row / a.Np, n = row - k * a.Np;
-    if (k < a.Ks && n < a.N) {
-      const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
-      if (wt) {
-        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
-      } else {
-        *reinterpret_cast<float4*>(outp + off) = v;
-      }
+    const bool ok = k < a.Ks && n < a.N;
+    const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + wc * 32 + q * 4;
+    if (wt) {
+      const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, ok ? (int)(off * 4) : (int)0x7ffffff0, 0, 16);   // sc1; dropped when out of range
+    } else if (ok) {
+      *reinterpret_cast<float4*>(outp + off) = v;
     }
   }
 }

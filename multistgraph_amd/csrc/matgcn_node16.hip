@@ -98,39 +98,7 @@ struct Node16Args {
 #endif
 };
 
-// ---- lab only: in-kernel phase stamps (s_memtime at wave granularity, kept in SGPRs, written once at the end) ----
-#ifdef NODE_LAB_STAMPS
-#define NODE_STAMPS 28
-struct NodeStamps {
-  unsigned int t[NODE_STAMPS];
-  __device__ __forceinline__ void at(int i) {
-    t[i] = (unsigned int)__builtin_amdgcn_s_memtime();
-    if (i == 0) t[24] = (unsigned int)__builtin_amdgcn_s_memrealtime();
-  }
-  __device__ __forceinline__ void flush(unsigned int* out) {
-    if (!out) return;
-    t[25] = (unsigned int)__builtin_amdgcn_s_memrealtime();
-    t[26] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
-    t[27] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
-    if ((threadIdx.x & 63) == 0) {
-      unsigned int* o = out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NODE_STAMPS;
-#pragma unroll
-      for (int i = 0; i < NODE_STAMPS; ++i) o[i] = t[i];
-    }
-  }
-};
-#define NODE_STAMP_DECL NodeStamps nst; for (int i_ = 0; i_ < NODE_STAMPS; ++i_) nst.t[i_] = 0;
-#define NODE_STAMP(i) nst.at(i)
-#define NODE_STAMP_ARG , nst
-#define NODE_STAMP_PARAM , NodeStamps& nst
-#define NODE_STAMP_FLUSH(a) nst.flush((a).stamps)
-#else
-#define NODE_STAMP_DECL
-#define NODE_STAMP(i)
-#define NODE_STAMP_ARG
-#define NODE_STAMP_PARAM
-#define NODE_STAMP_FLUSH(a)
-#endif
+// (in-kernel phase stamps of the lab builds: NODE_STAMP* macros, matgcn_internal.h)
 
 // Gate non-linearities of the step kernels.  The node kernels' epilogues are VALU-bound stretches in which the matrix
 // pipe idles (round 4, tools/labs/stamps_r04.py: the 16 sigmoids per lane of k_gate16 took 8 200 cycles with two
