@@ -348,7 +348,9 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
  * first use; forked from and joined back into the caller's stream with events, so the caller still sees one
  * in-order stream).  matgcn_set_wavefront(0) serialises everything on the caller's stream instead - same kernels,
  * same results; used to time one kernel alone.  (A lock-step pairing of the chains through per-kernel events was
- * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting. */
+ * measured and rejected: the cross-stream waits cost more than the pairing gains.)  Returns the previous setting.
+ * matgcn_set_wavefront(2) is a lab switch (round 4, measured and rejected: 8.3 against 6.8 ms): the graph mixes of all
+ * chains form one global order so that a mix only ever runs beside the other chain's node kernel; same results. */
 int matgcn_set_wavefront(int enabled);
 
 /* Lazy prepare.  By default `prepared` is complete, in stream order, when matgcn_prepare returns.  With

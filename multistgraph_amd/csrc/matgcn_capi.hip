@@ -331,6 +331,7 @@ struct Wavefront {
   hipEvent_t step[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l finished step t
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
   hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
+  hipEvent_t mixz[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l has mixed z*h (phase 2 of its step t): the mix token's second stop
   hipEvent_t bail[2 * MATGCN_MAX_LAYERS + 3];      // error exits: one per library stream (join_library_streams)
 };
 // one set per device ordinal: a HIP stream / event belongs to the device that was current when it was created, so a
@@ -442,6 +443,7 @@ int wavefront_ready() {
       HIP_OK(hipEventCreateWithFlags(&g_wf.step[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.xdone[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.mixed[l][t], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&g_wf.mixz[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.bready[l][t], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&g_wf.bxcol[l][t], hipEventDisableTiming));
     }
@@ -832,9 +834,11 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
     }
   }
   if (!P.gcnOff) RETURN_IF(fold_x0(c, x0p, P.T, c.s));
+  const long stepRows = (long)P.B * P.Np * H;     // one step of a time-major sequence
+  auto chain_stream = [&](int l) { return (l == 0 || !multi) ? c.s : W.chain[l]; };
+  // ---- per layer: state, padding rows ----
   for (int l = 0; l < P.L; ++l) {
-    hipStream_t cs = (l == 0 || !multi) ? c.s : W.chain[l];
-    hipStream_t xs = multi ? W.xpart[l] : c.s;
+    hipStream_t cs = chain_stream(l);
     RETURN_IF(zero_async(c.ws + P.oZHx[l], (long)P.B * P.Np * H, cs));
     if (P.Np != P.N) {
       hipLaunchKernelGGL(k_zero_pad_rows, dim3(blocks_for((size_t)P.B * P.T * (P.Np - P.N) * H)), dim3(256), 0, cs,
@@ -851,72 +855,107 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
                          P.Np, H);
       CHECK_LAUNCH();
     }
+  }
+  // ---- the mix token (matgcn_set_wavefront(2), round 4) -------------------------------------------------------------
+  // In the free-running wavefront every kernel of a chain is stretched by whatever the other chain happens to run beside
+  // it (in-situ events: k_mix 41 -> 75 us on average, the wall is the sum of one chain's stretched kernels).  A graph mix
+  // is MFMA-bound with HBM idle, a node kernel streams weights with the matrix pipe a third busy, and one node workgroup
+  // fits beside the five mix workgroups of a CU (5 x 56 + 2 x 112 registers): they are complementary - two mixes, or two
+  // node kernels, are not.  With the token the graph mixes of ALL chains form one global order (every mix waits for the mix
+  // enqueued before it, on whatever stream that was); the node kernels stay free on their chains.  So a mix never runs
+  // beside another mix, and the node kernel that follows a mix runs beside the next chain's mix.  The steps are enqueued
+  // in global order (layer l runs `lag` steps behind layer l-1) so that every event is recorded before it is waited for.
+  const bool token = multi && g_wavefront_mode == 2 && !P.gcnOff && P.Ks > 0;
+  hipEvent_t lastMix = nullptr;
+  hipStream_t lastMixStream = nullptr;
+  auto mix_phase = [&](int l, int t, int phase, const Node16Args* res, hipStream_t cs) -> int {
+    if (token && lastMix && lastMixStream != cs) HIP_OK(hipStreamWaitEvent(cs, lastMix, 0));
+    RETURN_IF(cell_phase(c, l, t, phase, nullptr, res, cs));
+    if (phase == 0 && ((multi && l + 1 < P.L) || token)) HIP_OK(hipEventRecord(W.mixed[l][t], cs));
+    if (phase == 2 && token) HIP_OK(hipEventRecord(W.mixz[l][t], cs));
+    if (token) { lastMix = phase == 0 ? W.mixed[l][t] : W.mixz[l][t]; lastMixStream = cs; }
+    return MATGCN_OK;
+  };
+  int nextChunk[MATGCN_MAX_LAYERS] = {0};
+  // ---- one step of one layer ----
+  auto enqueue_step = [&](int l, int t) -> int {
+    hipStream_t cs = chain_stream(l);
+    hipStream_t xs = multi ? W.xpart[l] : c.s;
     const float* below = (l == 0) ? nullptr : c.ws + P.oSeq[l - 1];
     float* seq = c.ws + P.oSeq[l];
-    const long stepRows = (long)P.B * P.Np * H;     // one step of a time-major sequence
-    int nextChunk = 0;
-    for (int t = 0; t < P.T; ++t) {
-      if (P.gcnOff) {
-        // ablation: the layer is a plain GRU cell on (x_t, h) (MultiATGCN.py:187-192,204): one launch per step
-        if (multi && l > 0) HIP_OK(hipStreamWaitEvent(cs, W.step[l - 1][t], 0));
-        Node16Args a;
-        memset(&a, 0, sizeof(a));
-        a.s = c.ws + P.oHx[l]; a.hout = c.ws + P.oHx[l];
-        a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = 0;
-        if (l == 0) fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0, nullptr, seq + t * stepRows, &a);
-        else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
-        {
-          ProfScope prof(MATGCN_PROF_RES, cs);
-          const dim3 grid(node_items(P.N, P.B, NODE_ROWS));
-          if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
-            const size_t at = (size_t)t * P.B * P.Np * H;
-            a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
-            hipLaunchKernelGGL((k_update16<2, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, cs, a);
-          } else {
-            hipLaunchKernelGGL((k_update16<2, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
-          }
-        }
-        CHECK_LAUNCH();
-        if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
-        continue;
-      }
-      if (l > 0 && t == nextChunk) {
-        // x-part chunk [t, t+nt) of this layer, as soon as the layer below has produced those steps; the first
-        // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
-        const int nt = chunk_steps(P, t);
-        nextChunk = t + nt;
-        // steps whose mixed rows the layer below has already written into this chunk's block (its recurrent mix of
-        // h_t at its step t+1): all but the sequence's last step
-        float* slot; long stride;
-        int mixedSteps = 0;
-        if (shared_mix_slot(c, l - 1, t, &slot, &stride)) mixedSteps = P.T - 1 - t < nt ? P.T - 1 - t : nt;
-        if (multi) {
-          if (mixedSteps == nt) HIP_OK(hipStreamWaitEvent(xs, W.mixed[l - 1][t + nt], 0));
-          else HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
-        }
-        RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs, mixedSteps));
-        if (multi) {
-          HIP_OK(hipEventRecord(W.xdone[l][t], xs));
-          HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
+    if (P.gcnOff) {
+      // ablation: the layer is a plain GRU cell on (x_t, h) (MultiATGCN.py:187-192,204): one launch per step
+      if (multi && l > 0) HIP_OK(hipStreamWaitEvent(cs, W.step[l - 1][t], 0));
+      Node16Args a;
+      memset(&a, 0, sizeof(a));
+      a.s = c.ws + P.oHx[l]; a.hout = c.ws + P.oHx[l];
+      a.rows = P.B; a.N = P.N; a.Np = P.Np; a.Ks = 0;
+      if (l == 0) fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0, nullptr, seq + t * stepRows, &a);
+      else fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, nullptr, seq + t * stepRows, &a);
+      {
+        ProfScope prof(MATGCN_PROF_RES, cs);
+        const dim3 grid(node_items(P.N, P.B, NODE_ROWS));
+        if (c.train) {   // training keeps z, r, hc of the dense cell (slots of the residual cell)
+          const size_t at = (size_t)t * P.B * P.Np * H;
+          a.svZ2 = c.train + c.R.oZ2[l] + at; a.svR2 = c.train + c.R.oR2[l] + at; a.svHC2 = c.train + c.R.oHC2[l] + at;
+          hipLaunchKernelGGL((k_update16<2, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, cs, a);
+        } else {
+          hipLaunchKernelGGL((k_update16<2, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, cs, a);
         }
       }
-      Node16Args res;
-      if (l == 0)
-        fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0,
-                      c.prm->weights_gru + (size_t)l * P.T + t, seq + t * stepRows, &res);
-      else
-        fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, c.prm->weights_gru + (size_t)l * P.T + t,
-                      seq + t * stepRows, &res);
-      RETURN_IF(cell_phase(c, l, t, 0, nullptr, &res, cs));
-      if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.mixed[l][t], cs));
-      // layer 0's weight streams are first read here: head fusion, the fold of x0 and the first mix ran beside their
-      // preparation (lazy prepare)
-      if (lazyPrep && multi && l == 0 && t == 0) RETURN_IF(prep_wait(cs, 1));
-      RETURN_IF(cell_phase(c, l, t, 1, nullptr, &res, cs));
-      RETURN_IF(cell_phase(c, l, t, 2, nullptr, &res, cs));
-      RETURN_IF(cell_phase(c, l, t, 3, nullptr, &res, cs));
+      CHECK_LAUNCH();
       if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
+      return MATGCN_OK;
     }
+    if (l > 0 && t == nextChunk[l]) {
+      // x-part chunk [t, t+nt) of this layer, as soon as the layer below has produced those steps; the first
+      // chunks are short (1, 1, 2 steps) so that this layer starts one step behind the layer below
+      const int nt = chunk_steps(P, t);
+      nextChunk[l] = t + nt;
+      // steps whose mixed rows the layer below has already written into this chunk's block (its recurrent mix of
+      // h_t at its step t+1): all but the sequence's last step
+      float* slot; long stride;
+      int mixedSteps = 0;
+      if (shared_mix_slot(c, l - 1, t, &slot, &stride)) mixedSteps = P.T - 1 - t < nt ? P.T - 1 - t : nt;
+      if (multi) {
+        if (mixedSteps == nt) HIP_OK(hipStreamWaitEvent(xs, W.mixed[l - 1][t + nt], 0));
+        else HIP_OK(hipStreamWaitEvent(xs, W.step[l - 1][t + nt - 1], 0));
+      }
+      RETURN_IF(hoist_x(c, l, below + t * stepRows, t, nt, xs, mixedSteps));
+      if (multi) {
+        HIP_OK(hipEventRecord(W.xdone[l][t], xs));
+        HIP_OK(hipStreamWaitEvent(cs, W.xdone[l][t], 0));
+      }
+    }
+    Node16Args res;
+    if (l == 0)
+      fill_res_args(c, l, x0p + (long)t * P.Np * P.C0, (long)P.T * P.Np * P.C0,
+                    c.prm->weights_gru + (size_t)l * P.T + t, seq + t * stepRows, &res);
+    else
+      fill_res_args(c, l, below + t * stepRows, (long)P.Np * H, c.prm->weights_gru + (size_t)l * P.T + t,
+                    seq + t * stepRows, &res);
+    RETURN_IF(mix_phase(l, t, 0, &res, cs));
+    // layer 0's weight streams are first read here: head fusion, the fold of x0 and the first mix ran beside their
+    // preparation (lazy prepare)
+    if (lazyPrep && multi && l == 0 && t == 0) RETURN_IF(prep_wait(cs, 1));
+    RETURN_IF(cell_phase(c, l, t, 1, nullptr, &res, cs));
+    RETURN_IF(mix_phase(l, t, 2, &res, cs));
+    RETURN_IF(cell_phase(c, l, t, 3, nullptr, &res, cs));
+    if (multi && l + 1 < P.L) HIP_OK(hipEventRecord(W.step[l][t], cs));
+    return MATGCN_OK;
+  };
+  // ---- global order: layer l runs `lag` steps behind layer l-1 (lag = T: layer after layer, the free-running wavefront's
+  // enqueue order - its events only tie a layer to the one below).  The x-part chunk of layer l that starts at step t waits
+  // for step t + nt (<= t + X_CHUNK) of the layer below, which must have been ENQUEUED by then: lag = X_CHUNK + 1. ----
+  const int lag = token ? X_CHUNK + 1 : P.T;
+  for (int g = 0; g < P.T + lag * (P.L - 1); ++g)
+    for (int l = 0; l < P.L; ++l) {
+      const int t = g - lag * l;
+      if (t >= 0 && t < P.T) RETURN_IF(enqueue_step(l, t));
+    }
+  // ---- per layer: final states, join ----
+  for (int l = 0; l < P.L; ++l) {
+    hipStream_t cs = chain_stream(l);
     if (finalsUser) {
       hipLaunchKernelGGL(k_unpack_rows, dim3(blocks_for((size_t)P.B * P.N * H)), dim3(256), 0, cs, c.ws + P.oHx[l],
                          finalsUser + (size_t)l * P.B * P.N * H, P.B, P.N, P.Np, H);
@@ -1117,7 +1156,7 @@ int matgcn_set_mix_precision(int mode) {
 
 int matgcn_set_wavefront(int mode) {
   const int prev = g_wavefront_mode;
-  g_wavefront_mode = mode != 0 ? 1 : 0;
+  g_wavefront_mode = (mode == 1 || mode == 2) ? mode : (mode != 0 ? 1 : 0);
   return prev;
 }
 

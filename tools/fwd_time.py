@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--serial", action="store_true")
+    ap.add_argument("--token", action="store_true", help="matgcn_set_wavefront(2): the graph mixes of all chains in one global order")
     ap.add_argument("--cache-prepared", action="store_true")
     ap.add_argument("--split", type=int, default=0, help="matgcn_set_batch_split(n)")
     ap.add_argument("--kernels", action="store_true", help="per-kernel launch averages, wavefront off (HIP events)")
@@ -32,6 +33,8 @@ def main():
     model.cache_prepared = bool(args.cache_prepared)
     if args.serial:
         _lib.load().matgcn_set_wavefront(0)
+    if args.token:
+        _lib.load().matgcn_set_wavefront(2)
     if args.split:
         _lib.load().matgcn_set_batch_split(args.split)
     x_np, y_np = syn.make_batch_arrays(w["batch"], w["nodes"], w["out"], 0, feat=2)
