@@ -23,7 +23,7 @@ Rank 0 prints ONE JSON line.  Two extra objects:
                  own), and `in_wavefront` repeats it for an instrumented forward of the timed configuration.
                  `traffic` / `mfma_util_pmc` are the HBM traffic per launch (FETCH_SIZE doubled as the gfx950
                  guide prescribes, + WRITE_SIZE) and the MFMA-busy fraction from the rocprofv3 PMC passes
-                 committed under profiles/ (tools/profile_r03.sh) - replayed ONLY when they were collected on the
+                 committed under profiles/ (tools/profile_run.sh) - replayed ONLY when they were collected on the
                  build that is running (`build_id`, a hash of the library's sources), else null.
                  `node_kernels` lists the next-largest kernels (k_gate16, k_update16, k_px16) the same way.
   median       - the §8(d) protocol: 20 warm-up + 100 forwards, each bracketed by HIP events on the caller's
@@ -132,7 +132,7 @@ PMC_KERNEL_NAMES = {"k_mix": "k_mix<1>", "k_gate": "k_gate16<false", "k_update":
 
 
 def load_pmc(build_id):
-    """the newest profiles/r*_pmc_kernels.json (tools/profile_r03.sh + tools/summarise_pmc.py) that was collected on
+    """the newest profiles/r*_pmc_kernels.json (tools/profile_run.sh + tools/summarise_pmc.py) that was collected on
     THIS build (`build_id`, a hash of the library's sources); PMC figures of another build are never replayed"""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")), reverse=True)

@@ -1,13 +1,13 @@
 #!/bin/bash
 # The round's evidence on one build, in two parts (each fits one gpurun call):
-#   final_r03.sh tests  [tag]   full GPU suite, smoke, bench lines of the three single-GPU workloads (+ training lines),
+#   final_run.sh tests  [tag]   full GPU suite, smoke, bench lines of the three single-GPU workloads (+ training lines),
 #                               host enqueue time, the 2-rank gloo rehearsal of bench.py's distributed branch
-#   final_r03.sh profile [tag]  rocprofv3 kernel stats (serial + default schedule, training step) and the PMC passes
+#   final_run.sh profile [tag]  rocprofv3 kernel stats (serial + default schedule, training step) and the PMC passes
 # Everything lands under gpurun_out/<tag>/ (and gpurun_out/prof_<tag>, pmc_train_<tag>); the summaries worth keeping are
-# copied into profiles/r03_* by hand afterwards.
+# copied into profiles/r<round>_* by hand afterwards.
 set -o pipefail
 PART=${1:-tests}
-TAG=${2:-r03final}
+TAG=${2:-final}
 O=gpurun_out/$TAG
 mkdir -p $O
 if [ "$PART" = "tests" ]; then
@@ -26,9 +26,9 @@ if [ "$PART" = "tests" ]; then
   bash tools/rehearse_2rank.sh > $O/rehearse.log 2>&1
   echo "rehearse rc=$?"; cp gpurun_out/rehearse/bench_2rank.json $O/rehearsal_2rank_gloo_one_gpu.json 2>/dev/null
 else
-  bash tools/profile_r03.sh $TAG > $O/profile.log 2>&1
+  bash tools/profile_run.sh $TAG > $O/profile.log 2>&1
   echo "profile rc=$?"; cat gpurun_out/prof_$TAG/pmc_kernels.txt
-  bash tools/pmc_train_r03.sh $TAG > $O/pmc_train.log 2>&1
+  bash tools/pmc_train_run.sh $TAG > $O/pmc_train.log 2>&1
   echo "pmc train rc=$?"; head -24 gpurun_out/pmc_train_$TAG/train_pmc_kernels.txt
   bash tools/profile_train.sh $TAG > $O/profile_train.log 2>&1
   echo "profile train rc=$?"

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--serial", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (16 = the reference's shipped batch_size)")
     ap.add_argument("--token", action="store_true", help="matgcn_set_wavefront(2): the graph mixes of all chains in one global order")
     ap.add_argument("--cache-prepared", action="store_true")
     ap.add_argument("--split", type=int, default=0, help="matgcn_set_batch_split(n)")
@@ -29,6 +30,8 @@ def main():
     from multistgraph_amd import _lib, synthetic as syn
     dev = torch.device("cuda", 0)
     w = dict(bench.WORKLOADS[args.workload])
+    if args.batch:
+        w["batch"] = args.batch
     model, df, cfg = bench.build_model(w, dev, 0)
     model.cache_prepared = bool(args.cache_prepared)
     if args.serial:

@@ -2,7 +2,7 @@
 # PMC passes over two training steps with every kernel alone on one stream (train_step.py ... serial), counters only:
 #   1. MFMA utilisation of every kernel of the step (forward that keeps activations + backward)
 #   2. LDS bank conflicts against LDS-active cycles (the GEMM staging the verdict asked about)
-# usage: pmc_train_r03.sh <tag>  -> gpurun_out/pmc_train_<tag>/{mfma,lds}/..., train_pmc_kernels.json
+# usage: pmc_train_run.sh <tag>  -> gpurun_out/pmc_train_<tag>/{mfma,lds}/..., train_pmc_kernels.json
 set -o pipefail
 TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # All the profiler passes a bench line's roofline object refers to (run on the GPU box through gpurun).
-#   usage: profile_r03.sh <tag>     -> gpurun_out/prof_<tag>/{stats_serial,stats_default,FETCH_SIZE,WRITE_SIZE,MFMA}
+#   usage: profile_run.sh <tag>     -> gpurun_out/prof_<tag>/{stats_serial,stats_default,FETCH_SIZE,WRITE_SIZE,MFMA}
 # 1/2  rocprofv3 --kernel-trace --stats of bench.py with the wavefront off (the configuration avg_launch_ms is measured
 #      in) and of the default command
 # 3-5  PMC passes over two serial-schedule forwards (counters only, no tracing domains; FETCH_SIZE and WRITE_SIZE need

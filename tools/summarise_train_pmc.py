@@ -1,5 +1,5 @@
 """Per-kernel MFMA utilisation and LDS bank-conflict share of a training step from two rocprofv3 PMC passes over
-serial-schedule steps (tools/pmc_train_r03.sh), stamped with the source id of the build.
+serial-schedule steps (tools/pmc_train_run.sh), stamped with the source id of the build.
 
 mfma_util         = SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (kernel cycles x 1024 SIMDs), kernel cycles =
                     GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs)
