@@ -530,6 +530,16 @@ int launch_mix(const Plan& P, const float* St, const float* X, long xTileStride,
   } else if (a.nK > MIX_FLUSH_MIN_NK) {   // more than 1 024 reduction indices: partial sums every 256 (k_mix's FLUSH)
     if (stepRole) hipLaunchKernelGGL((k_mix<1, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_mix<0, true>), grid, dim3(256), 0, s, a);
+#ifndef MIX_C32_MAX_COLTILES
+#define MIX_C32_MAX_COLTILES 16    // column tiles (batch rows of a step mix) up to which the 64 x 32-tile kernel runs; 0: never
+                                   // (round 4, BM 403: B = 16 20.8 -> 18.1 us per launch, forward 3.69 -> 3.56 ms; B = 32 no gain per
+                                   //  launch and the forward 2 % SLOWER; DC 237 at B = 16 unchanged: profiles/r04_small_batch_lab.log)
+#endif
+  } else if (nColTiles <= MIX_C32_MAX_COLTILES && xTileStride % 4 == 0 && ldX >= 64) {
+    // small batches (the reference ships batch_size 16): twice the workgroups of half the width
+    const dim3 g2((unsigned)(a.nRowTiles * nColTiles * 2));
+    if (stepRole) hipLaunchKernelGGL(k_mix_c32<1>, g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_mix_c32<0>, g2, dim3(256), 0, s, a);
   } else if (stepRole) {
     hipLaunchKernelGGL(k_mix<1>, grid, dim3(256), 0, s, a);
   } else {
@@ -610,7 +620,9 @@ int node_kernels_ready(int ldsBytes) {
   // 32-row work items for batches of at most 32 rows (the halves of the batch-split forward)
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, 32>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, 32>), at, UPDATE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<4>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<2>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<1>), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
 }
@@ -660,7 +672,10 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
   a.pxOut = c.ws + P.oPX[l] + (size_t)t0 * P.N * P.RB * NODE_PX_BLOCK;
   a.steps = nt; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks; a.B = P.B;
   ProfScope prof(MATGCN_PROF_PX, s);
-  hipLaunchKernelGGL(k_px16, dim3((unsigned)(rup(P.N, 8) * nt * P.RB)), dim3(512), P.nodeLds, s, a);
+  const dim3 grid((unsigned)(rup(P.N, 8) * nt * P.RB));
+  if (P.B <= 16) hipLaunchKernelGGL(k_px16<1>, grid, dim3(512), P.nodeLds, s, a);         // row tiles that hold batch rows
+  else if (P.B <= 32) hipLaunchKernelGGL(k_px16<2>, grid, dim3(512), P.nodeLds, s, a);
+  else hipLaunchKernelGGL(k_px16<4>, grid, dim3(512), P.nodeLds, s, a);
   return launch_ok();
 }
 
@@ -718,7 +733,14 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   const bool save = c.train != nullptr && res != nullptr;
   // a batch of at most 32 rows (the halves of the batch-split forward) runs the 32-row instantiations: a 64-row tile
   // would be half padding
-  const bool rows32 = NODE_ROWS == 64 && P.B <= 32 && !save && res != nullptr && !raw && !g_node_bf16_now;
+  // ... and so does a graph of at most NODE_ROWS32_MAX_NODES nodes at any batch size: 237 (node, 64-row) items leave half of
+  // the chip's 512 workgroup slots empty; as (node, 32-row) items they fill 474 of them (round 3 measured the compile-time
+  // variant at N = 237: gate 19.4 -> 18.5 us, update 24.4 -> 22.5 us; round 4 picks it at run time)
+#ifndef NODE_ROWS32_MAX_NODES
+#define NODE_ROWS32_MAX_NODES 256
+#endif
+  const bool rows32 = NODE_ROWS == 64 && (P.B <= 32 || P.N <= NODE_ROWS32_MAX_NODES) && !save && res != nullptr && !raw &&
+                      !g_node_bf16_now;
   const dim3 grid(node_items(P.N, P.B, rows32 ? 32 : NODE_ROWS));   // (node, row block) work items, XCD-paired per node
 #ifdef NODE_LAB_STAMPS
   a.stamps = (g_lab_stamp_kinds & 1) ? lab_stamp_slot(grid.x) : nullptr;

@@ -606,12 +606,8 @@ __global__ __launch_bounds__(256) void k_build_xa0(const float* __restrict__ x0p
 // (tests/golden/fp64_gap.npz; a blocked CPU sgemm sums K in blocks of a few hundred).  With FLUSH the chain is cut every
 // MIX_FLUSH_TILES K-tiles (256 reduction indices): partial sums go to a second accumulator set.  Launched for nK > 64 only,
 // so every graph of at most 1 024 nodes - the headline's 403 - keeps its kernel and its bits.
-#ifndef MIX_PRIO_ROTATE
-#define MIX_PRIO_ROTATE 0
-#endif
-#ifndef MIX_PRIO_SHIFT
-#define MIX_PRIO_SHIFT 1      // the priority moves on every 2^MIX_PRIO_SHIFT K-tiles
-#endif
+// (round 4, measured and rejected: rotating the wave priority with the K-tile index by dispatch round so that the five
+//  workgroups of a CU leave together - they do, and every one is slower: 43.0 vs 41.3 us, profiles/r04_mix_stamps_lab.log)
 #ifndef MIX_FLUSH_TILES
 #define MIX_FLUSH_TILES 16
 #endif
@@ -704,19 +700,6 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   const int nKrun = a.nK;
 #endif
   for (int it = 0; it < nKrun; it += 2) {
-#if MIX_PRIO_ROTATE
-    // The five workgroups of a CU share each SIMD's matrix pipe, and the arbiter prefers the OLDEST wave: in-kernel stamps
-    // (round 4, tools/labs/stamps_mix_r04.py) show the workgroups of one CU leaving one after the other between 58 k and
-    // 85 k cycles for 66.5 k cycles of MFMA work - the last ones alone on their SIMD, where a single wave cannot keep the
-    // pipe busy.  Priority outranks age: rotating it with the K-tile index by the workgroup's dispatch round (ids 256 apart
-    // share a CU) hands the top priority round, so the five progress together and leave together.
-    switch (((it >> MIX_PRIO_SHIFT) + (int)(blockIdx.x >> 8)) & 3) {   // (s_setprio takes an immediate)
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
     mma(0);                                               // tile it
     *reinterpret_cast<float4*>(&As[1][stPos]) = ra0;      // tile it+1 (a clamped copy past the end: unused)
     *reinterpret_cast<float4*>(&Bs[1][stPos]) = rb0;
@@ -811,6 +794,119 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs a) {
   NODE_STAMP(8);   // stores acknowledged
 #endif
   NODE_STAMP_FLUSH(a);
+}
+
+// -------------------------------------------------------------------------------------------------
+// 5a''. the same mix with 64-row x 32-column tiles: small batches
+// -------------------------------------------------------------------------------------------------
+// The reference ships batch_size 16 (MultiATGCN.json:12).  There k_mix has 20 x 16 = 320 workgroups for 256 CUs - 64 CUs get
+// two, the launch takes 20.6 us for a quarter of the B = 64 work (41 us).  With half-width column tiles there are 640
+// workgroups (2.5 per CU, five waves per CU on average as before, but the longest CU holds 3 halves instead of 2 wholes).
+// Same pipeline as k_mix (K-step 16 through LDS, two K-tiles ahead in registers, rotated rows); a wave owns 32 rows x 16
+// columns = 2 x 1 accumulators, the B tile uses columns 0..31 of its 64-wide LDS rows (both halves of the workgroup request
+// it - duplicate stores of equal values).  Launched for at most 32 column tiles (B <= 32).
+template <int ROLE>
+__global__ __launch_bounds__(256) void k_mix_c32(MixArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][16 * 64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * 64];
+  const int id = blockIdx.x, nCt2 = 2 * a.nColTiles;
+  int ct2, rowTile;
+  if ((nCt2 & 7) == 0) {
+    const int xcd = id & 7, jj = id >> 3, cpx = nCt2 >> 3;
+    rowTile = jj % a.nRowTiles;
+    ct2 = xcd * cpx + jj / a.nRowTiles;
+  } else {
+    rowTile = id % a.nRowTiles;
+    ct2 = id / a.nRowTiles;
+  }
+  const int colTile = ct2 >> 1, half = ct2 & 1;
+  const int row0 = rowTile * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1, j = lane & 15, kq = lane >> 4;
+  const int kk = tid >> 4, sg = tid & 15, sgB = sg & 7;
+  const int part = blockIdx.y;
+  const float* ap = a.St + (size_t)part * a.aPartStride + (size_t)kk * a.ldS + row0 + sg * 4;
+  const float* bp = a.X + (size_t)part * a.xPartStride + (size_t)colTile * a.xTileStride + (size_t)kk * a.ldX + half * 32 + sgB * 4;
+  const int stPosA = kk * 64 + (((sg + 4 * (kk & 3)) & 15) << 2);
+  const int stPosB = kk * 64 + (((sgB + 4 * (kk & 3)) & 15) << 2);
+  const int last = a.nK - 1;
+  auto ldA = [&](int t) { return *reinterpret_cast<const float4*>(ap + (size_t)min(t, last) * 16 * a.ldS); };
+  auto ldB = [&](int t) { return *reinterpret_cast<const float4*>(bp + (size_t)min(t, last) * 16 * a.ldX); };
+  float4 ra0, rb0, ra1, rb1;
+  {
+    const float4 a0 = ldA(0), b0 = ldB(0);
+    __builtin_amdgcn_sched_barrier(0);
+    ra0 = ldA(1); rb0 = ldB(1); ra1 = ldA(2); rb1 = ldB(2);
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<float4*>(&As[0][stPosA]) = a0;
+    *reinterpret_cast<float4*>(&Bs[0][stPosB]) = b0;
+  }
+  __syncthreads();
+  f32x4 acc[2];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+  const int rotA0 = (wr * 32 + j + 16 * kq) & 63, rotA1 = (wr * 32 + 16 + j + 16 * kq) & 63;
+  const int rotB0 = (wc * 16 + j + 16 * kq) & 63;
+  auto mma = [&](int cur) {
+    const float* A = &As[cur][kq * 64];
+    const float* Bm = &Bs[cur][kq * 64];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float a0 = A[s4 * 256 + rotA0], a1 = A[s4 * 256 + rotA1];
+      const float b0 = Bm[s4 * 256 + rotB0];
+      acc[0] = MFMA16(a0, b0, acc[0]);
+      acc[1] = MFMA16(a1, b0, acc[1]);
+    }
+  };
+  for (int it = 0; it < a.nK; it += 2) {
+    mma(0);
+    *reinterpret_cast<float4*>(&As[1][stPosA]) = ra0;
+    *reinterpret_cast<float4*>(&Bs[1][stPosB]) = rb0;
+    ra0 = ldA(it + 3); rb0 = ldB(it + 3);
+    __syncthreads();
+    if (it + 1 < a.nK) {
+      mma(1);
+      *reinterpret_cast<float4*>(&As[0][stPosA]) = ra1;
+      *reinterpret_cast<float4*>(&Bs[0][stPosB]) = rb1;
+      ra1 = ldA(it + 4); rb1 = ldB(it + 4);
+      __syncthreads();
+    }
+  }
+  // epilogue: the wave's 32 x 16 tile through LDS ([32 rows][4 slots], slot ^ (row & 3)), 16-byte write-through stores
+  float* stg = (w < 2 ? &As[0][0] : &Bs[0][0]) + (w & 1) * 1024;
+  {
+    const int jq = j >> 2, jr = j & 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int lrow = p * 16 + 4 * kq + e;
+        stg[lrow * 16 + ((jq ^ (lrow & 3)) << 2) + jr] = acc[p][e];
+      }
+  }
+  const bool wt = a.outFloats > 0 && a.outFloats < (1L << 29);
+  float* outp = a.out + (size_t)part * a.outPartStride;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, wt ? (int)(a.outFloats * 4) : 0, 0x00020000);
+  float4 v2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lrow = u * 16 + (lane >> 2), q = lane & 3;
+    v2[u] = *reinterpret_cast<const float4*>(&stg[lrow * 16 + ((q ^ (lrow & 3)) << 2)]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lrow = u * 16 + (lane >> 2), q = lane & 3;
+    const float4 v = v2[u];
+    const int row = row0 + wr * 32 + lrow;
+    const int k = row / a.Np, n = row - k * a.Np;
+    const bool ok = k < a.Ks && n < a.N;
+    const size_t off = (size_t)colTile * a.sT + (size_t)n * a.sN + (size_t)k * a.sK + half * 32 + wc * 16 + q * 4;
+    if (wt) {
+      const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, ok ? (int)(off * 4) : (int)0x7ffffff0, 0, 16);   // sc1; dropped when out of range
+    } else if (ok) {
+      *reinterpret_cast<float4*>(outp + off) = v;
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------------

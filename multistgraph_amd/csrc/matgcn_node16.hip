@@ -560,6 +560,9 @@ __device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int K
   return *reinterpret_cast<const float4*>(&Gs[(row * 16 * Ks + ((q & ~15) | ((q ^ i) & 15))) * 4]);
 }
 
+// NRT: 16-row tiles of the 64-row block that hold batch rows (4; 2 / 1 for batches of at most 32 / 16 rows - the reference
+// ships batch_size 16, where three of the four row tiles were padding: 64 us per launch at ANY batch size until round 4)
+template <int NRT>
 __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;
@@ -588,9 +591,9 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   }
   const int o0 = 16 * w + j, o1 = 16 * (w + 8) + j;
   const float b0 = p.bias[(size_t)n * 192 + o0], b1 = two ? p.bias[(size_t)n * 192 + o1] : 0.f;
-  f32x4 acc0[4], acc1[4];
+  f32x4 acc0[NRT], acc1[NRT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
+  for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
   __syncthreads();
   for (int g0 = 0; g0 < nG; g0 += PX16_RING) {
 #pragma unroll
@@ -600,26 +603,26 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
       wr0[r] = wp0[(size_t)min(g + PX16_RING, nG - 1) * 12 * 64];
       wr1[r] = wp1[(size_t)min(g + PX16_RING, nG - 1) * 12 * 64];
       if (g < nG) {
-        float4 av[4];
+        float4 av[NRT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) av[rt] = a_frag(Hs, Gs, p.Ks, rt, g, j, kq);
+        for (int rt = 0; rt < NRT; ++rt) av[rt] = a_frag(Hs, Gs, p.Ks, rt, g, j, kq);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
         if (two) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
         }
       }
     }
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   // the accumulators leave as they are: one 1 KB wave row per (column tile, row tile)
   float4* dst = reinterpret_cast<float4*>(p.pxOut) + (((size_t)tl * p.N + n) * RB + rb) * (NODE_PX_BLOCK / 4) + lane;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < NRT; ++rt) {
     dst[((size_t)w * 4 + rt) * 64] = make_float4(acc0[rt][0], acc0[rt][1], acc0[rt][2], acc0[rt][3]);
     if (two) dst[((size_t)(w + 8) * 4 + rt) * 64] = make_float4(acc1[rt][0], acc1[rt][1], acc1[rt][2], acc1[rt][3]);
   }
