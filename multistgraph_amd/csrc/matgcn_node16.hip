@@ -582,7 +582,9 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   a.s = p.x + (size_t)tl * p.B * p.Np * 64;
   a.g = p.g + (size_t)tl * p.B * p.Ks * 64; a.gNodeStride = (long)p.steps * p.B * p.Ks * 64;
   a.rows = p.B; a.Np = p.Np; a.Ks = p.Ks;
-  stage_node_tile(a, n, rowBase, Hs, Gs);
+  // the first weight groups and the bias depend on nothing this kernel stages: requested BEFORE the A tile, they are in
+  // flight while the tile's 64 KB go global -> registers -> LDS (round 4: no measurable gain, 69.6 us either way; a ring of
+  // 6 groups instead of 4 is slower, 72 us: profiles/r04_small_batch_lab.log)
   float4 wr0[PX16_RING], wr1[PX16_RING];
 #pragma unroll
   for (int r = 0; r < PX16_RING; ++r) {
@@ -591,6 +593,8 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   }
   const int o0 = 16 * w + j, o1 = 16 * (w + 8) + j;
   const float b0 = p.bias[(size_t)n * 192 + o0], b1 = two ? p.bias[(size_t)n * 192 + o1] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  stage_node_tile(a, n, rowBase, Hs, Gs);
   f32x4 acc0[NRT], acc1[NRT];
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
