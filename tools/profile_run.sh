@@ -12,9 +12,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step --serial-streams > $OUT/bench_serial.json 2> $OUT/bench_serial.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step --no-batch16 --serial-streams > $OUT/bench_serial.json 2> $OUT/bench_serial.err
 echo "[profile] serial stats rc=$?" | tee -a $OUT/progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step > $OUT/bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step --no-batch16 > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "[profile] default stats rc=$?" | tee -a $OUT/progress.log
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/tools/one_forward.py > $OUT/$C.log 2>&1
