@@ -620,6 +620,8 @@ int node_kernels_ready(int ldsBytes) {
   // 32-row work items for batches of at most 32 rows (the halves of the batch-split forward)
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<false, 32>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, 32>), at, UPDATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true, 32>), at, GATE_LDS));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, 32>), at, UPDATE_SAVE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<4>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<2>), at, ldsBytes));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<1>), at, ldsBytes));
@@ -739,7 +741,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
 #ifndef NODE_ROWS32_MAX_NODES
 #define NODE_ROWS32_MAX_NODES 256
 #endif
-  const bool rows32 = NODE_ROWS == 64 && (P.B <= 32 || P.N <= NODE_ROWS32_MAX_NODES) && !save && res != nullptr && !raw &&
+  // (round 4: the training instantiations too - at the shipped batch size 16 the training forward ran 64-row tiles)
+  const bool rows32 = NODE_ROWS == 64 && (P.B <= 32 || P.N <= NODE_ROWS32_MAX_NODES) && res != nullptr && !raw &&
                       !g_node_bf16_now;
   const dim3 grid(node_items(P.N, P.B, rows32 ? 32 : NODE_ROWS));   // (node, row block) work items, XCD-paired per node
 #ifdef NODE_LAB_STAMPS
@@ -755,7 +758,8 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
   if (phase == 1) {
     a.s = Hx; a.w = bf ? c.ws + P.oW16g[l] : c.prep + P.oWg[l]; a.zh = ZHx; a.r = R; a.raw = raw;
     ProfScope prof(MATGCN_PROF_GATE, s);
-    if (rows32) hipLaunchKernelGGL((k_gate16<false, 32>), grid, dim3(512), GATE_LDS / 2, s, a);
+    if (rows32 && save) hipLaunchKernelGGL((k_gate16<true, 32>), grid, dim3(512), GATE_LDS / 2, s, a);
+    else if (rows32) hipLaunchKernelGGL((k_gate16<false, 32>), grid, dim3(512), GATE_LDS / 2, s, a);
     else if (bf) hipLaunchKernelGGL((k_gate16<false, NODE_ROWS, true>), grid, dim3(512), GATE_LDS, s, a);
     else if (save) hipLaunchKernelGGL((k_gate16<true, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
     else hipLaunchKernelGGL((k_gate16<false, NODE_ROWS>), grid, dim3(512), GATE_LDS, s, a);
@@ -767,16 +771,15 @@ int cell_phase(const Ctx& c, int l, int t, int phase, float* raw, const Node16Ar
     a.xt = res->xt; a.xRowStride = res->xRowStride; a.C = res->C; a.Cpad = res->Cpad;
     a.rg = res->rg; a.rgb = res->rgb; a.ru = res->ru; a.rub = res->rub;
     a.blend = res->blend; a.seq = res->seq; a.seqRowStride = res->seqRowStride;
-    if (rows32) hipLaunchKernelGGL((k_update16<1, false, 32>), grid, dim3(512), UPDATE_LDS / 2, s, a);
-    else if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
-    else if (save) {
-      if (c.dropMask && l == P.L - 1 && t >= P.T - P.headT && a.seq) {   // the head's dropout rides in the sequence store
-        a.dropMask = c.dropMask + (size_t)(t - (P.T - P.headT)) * P.N * H;
-        a.dropRowStride = (long)P.headT * P.N * H;
-        a.seqDrop = c.train + c.R.oSeqDrop + (a.seq - (c.ws + P.oSeq[l]));
-      }
-      hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, s, a);
+    if (save && c.dropMask && l == P.L - 1 && t >= P.T - P.headT && a.seq) {   // the head's dropout rides in the sequence store
+      a.dropMask = c.dropMask + (size_t)(t - (P.T - P.headT)) * P.N * H;
+      a.dropRowStride = (long)P.headT * P.N * H;
+      a.seqDrop = c.train + c.R.oSeqDrop + (a.seq - (c.ws + P.oSeq[l]));
     }
+    if (rows32 && save) hipLaunchKernelGGL((k_update16<1, true, 32>), grid, dim3(512), UPDATE_SAVE_LDS / 2, s, a);
+    else if (rows32) hipLaunchKernelGGL((k_update16<1, false, 32>), grid, dim3(512), UPDATE_LDS / 2, s, a);
+    else if (bf) hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS, true>), grid, dim3(512), UPDATE_LDS, s, a);
+    else if (save) hipLaunchKernelGGL((k_update16<1, true, NODE_ROWS>), grid, dim3(512), UPDATE_SAVE_LDS, s, a);
     else hipLaunchKernelGGL((k_update16<1, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
   } else {
     hipLaunchKernelGGL((k_update16<0, false, NODE_ROWS>), grid, dim3(512), UPDATE_LDS, s, a);
