@@ -1,16 +1,17 @@
 #!/bin/bash
 # rocprofv3 kernel stats of three training steps on the SERIAL schedule (every kernel alone on the chip): the kernels' own durations
-#   usage: prof_train_serial.sh <tag> [library] [workload]
+#   usage: prof_train_serial.sh <tag> [library] [workload] [batch]
 set -o pipefail
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 [ -n "$2" ] && export MATGCN_LIB=$R/$2
 W=${3:-bm403}
+BATCH=${4:-}
 OUT=$R/gpurun_out/prof_train_serial_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/train_step.py $W 3 serial > $OUT/steps.log 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/train_step.py $W 3 serial $BATCH > $OUT/steps.log 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 python3 - $OUT/kernel_stats.csv <<'PY'

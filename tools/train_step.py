@@ -1,5 +1,5 @@
 """Training steps of the bench workload (default Baltimore 403, B=64): forward_train + backward through the plugin
-surface (calculate_loss().backward()), timed with HIP events.  usage: train_step.py [workload] [steps] [serial]
+surface (calculate_loss().backward()), timed with HIP events.  usage: train_step.py [workload] [steps] [serial|wave] [batch]
 (serial: matgcn_set_wavefront(0) - every kernel alone on one stream, so a profiler's durations are the kernels' own)"""
 import os, sys
 import torch
@@ -10,6 +10,8 @@ from multistgraph_amd import synthetic as syn
 name = sys.argv[1] if len(sys.argv) > 1 else "bm403"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 w = dict(bench.WORKLOADS[name])
+if len(sys.argv) > 4:
+    w["batch"] = int(sys.argv[4])      # e.g. 16, the reference's shipped batch_size
 dev = torch.device("cuda:0")
 model, df, cfg = bench.build_model(w, dev, 0)
 model.train()
