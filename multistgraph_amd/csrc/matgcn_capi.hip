@@ -47,7 +47,7 @@ struct Plan {
   long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
   long wxStride;
   int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], nGx[MATGCN_MAX_LAYERS];
-  int nodeLds;                // dynamic LDS bytes of k_px16 (whole 64-row tile: x slots + mixed slots)
+  int nodeLds;                // dynamic LDS bytes of k_px16 (three 16 KB K chunks of its 64-row tile)
   int RB;                     // 64-row blocks of the batch: the unit of the fragment-ordered PX / R blocks
   long preparedFloats;
   // workspace offsets (floats); state buffers are per layer so that layers can run concurrently
@@ -136,7 +136,11 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   }
   P->oHead = take((long)P->headT * H * 32 * P->NTc);
   P->preparedFloats = o;
+#if PX16_PIPELINE
+  P->nodeLds = 3 * 64 * 64 * (int)sizeof(float);   // the x-row chunk + two ping-pong chunks of mixed rows
+#else
   P->nodeLds = (64 * 64 + 64 * 64 * (P->Ks > 1 ? P->Ks : 1)) * (int)sizeof(float);
+#endif
   P->RB = (P->B + 63) / 64;
   // workspace
   o = 0;

@@ -49,6 +49,9 @@
 #ifndef PX16_RING
 #define PX16_RING 4        // k_px16: two rings (two column tiles per wave)
 #endif
+#ifndef PX16_PIPELINE
+#define PX16_PIPELINE 1    // k_px16 stages its A tile in K chunks under the MFMAs (0: whole tile first, the round-3 form)
+#endif
 #ifndef NODE_ROWS
 #define NODE_ROWS 64       // rows (batch items) of one (node, row block) work item of k_gate16 / k_update16: 64 or 32.
                            // The fragment-ordered PX / R blocks stay 64-row blocks either way (a 32-row item is the
@@ -594,8 +597,80 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   const int o0 = 16 * w + j, o1 = 16 * (w + 8) + j;
   const float b0 = p.bias[(size_t)n * 192 + o0], b1 = two ? p.bias[(size_t)n * 192 + o1] : 0.f;
   __builtin_amdgcn_sched_barrier(0);
-  stage_node_tile(a, n, rowBase, Hs, Gs);
   f32x4 acc0[NRT], acc1[NRT];
+#if PX16_PIPELINE
+  // the A tile goes through LDS in 16 KB K chunks (chunk 0 = the x rows, chunk c = mixed slot c-1) on the schedule of
+  // node_k_loop: chunk c+2 is written to LDS and chunk c+4 requested while chunk c feeds the matrix pipe - the tile's
+  // 64 KB no longer arrive before the first MFMA.  Both weight rings keep their one-chunk lead (refilled as consumed).
+  const int Ks = p.Ks;
+  float* Gb = Gs;
+  constexpr int CH = 64 * 64;
+  const ChunkStage<64> cs = chunk_stage<64>(a, n, rowBase);
+  float4 hS[2], st[2][2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+    hS[it] = *reinterpret_cast<const float4*>(a.s + ((size_t)cs.g[it] * a.Np + n) * 64 + cs.sq * 4);
+  chunk_load<64>(cs, Ks, 1, st[1]);
+  chunk_load<64>(cs, Ks, 2, st[0]);
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
+  auto chunk = [&](const float* buf, int c) {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl) {
+      const int g = 4 * c + gl;
+      const float4 wv0 = wr0[gl], wv1 = wr1[gl];
+      wr0[gl] = wp0[(size_t)min(g + 4, nG - 1) * 12 * 64];
+      wr1[gl] = wp1[(size_t)min(g + 4, nG - 1) * 12 * 64];
+      float4 av[NRT];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) av[rt] = tile[(rt * 16 + j) * 16 + ((4 * gl + kq) ^ j)];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
+      if (two) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
+      }
+    }
+  };
+  chunk_store<64>(Hs, cs, hS);
+  __syncthreads();
+  if (Ks > 0) {
+    chunk(Hs, 0);
+    chunk_store<64>(Gb, cs, st[1]);
+    if (Ks > 1) chunk_store<64>(Gb + CH, cs, st[0]);
+    chunk_load<64>(cs, Ks, 3, st[1]);
+    chunk_load<64>(cs, Ks, 4, st[0]);
+    __syncthreads();
+    for (int c = 1; c < Ks; c += 2) {
+      chunk(Gb, c);
+      __syncthreads();
+      if (c + 2 <= Ks) chunk_store<64>(Gb, cs, st[1]);
+      chunk_load<64>(cs, Ks, c + 4, st[1]);
+      if (c + 1 < Ks) {
+        chunk(Gb + CH, c + 1);
+        __syncthreads();
+        if (c + 3 <= Ks) chunk_store<64>(Gb + CH, cs, st[0]);
+        chunk_load<64>(cs, Ks, c + 5, st[0]);
+      }
+    }
+  }
+  if (Ks & 1) chunk(Gb, Ks);
+  else chunk(Ks > 0 ? Gb + CH : Hs, Ks);
+#else
+  stage_node_tile(a, n, rowBase, Hs, Gs);
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
   __syncthreads();
@@ -631,6 +706,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
       }
     }
   }
+#endif
   // the accumulators leave as they are: one 1 KB wave row per (column tile, row tile)
   float4* dst = reinterpret_cast<float4*>(p.pxOut) + (((size_t)tl * p.N + n) * RB + rb) * (NODE_PX_BLOCK / 4) + lane;
 #pragma unroll
