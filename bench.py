@@ -41,7 +41,13 @@ import statistics
 import sys
 import time
 
-import torch
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The path runs its layer chains, the hoisted
+# x parts and the backward's side work on streams of its own; once an RCCL communicator has taken queues as well, two chains
+# share one and serialise: forward 8.0 instead of 6.8 ms under an initialised process group, 6.8 with 8 queues (10 and more
+# cost the training step 20 %: profiles/r04_rccl_queues_lab.log).  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -248,13 +254,15 @@ def in_situ_kernel_times(model, batch, wavefront=True, forwards=1):
     return out
 
 
-def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None, ctl=None):
+def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None, ctl=None, do_exchange=None):
     """One optimisation step as TrafficStateExecutor._train_epoch runs it (traffic_state_executor.py:411-422):
     loss = model.calculate_loss(batch); loss.backward(); optimizer.step() - forward_train + backward on the HIP
     path, Adam in torch.  With more than one rank every rank steps on its own batch shard and the
     gradients meet in ONE flat-bucket all-reduce (RCCL over xGMI) before the optimizer, as BASELINE config 4 asks.
     Reported beside the headline; runs last because it moves the weights."""
     from multistgraph_amd import sharding
+    if do_exchange is None:
+        do_exchange = world > 1    # (True with ONE rank: the RCCL rehearsal of tools/rehearse_rccl_1rank.sh)
     model.train()
     model.cache_prepared = True
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -270,10 +278,10 @@ def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None, ctl
             loss.backward()
             ev[2].record()
         except Exception as exc:   # noqa: BLE001
-            if world == 1:
+            if not do_exchange:
                 raise
             failure = exc
-        if world > 1:
+        if do_exchange:
             # the gradient exchange is a collective: a rank that failed its local step must not leave the others waiting
             # in it.  Every rank votes on a CPU (gloo) control group before EVERY exchange (4 bytes, negligible next to a
             # 24 ms step); one failure makes ALL ranks give the section up.
@@ -296,13 +304,13 @@ def train_step_times(model, batch, w, warm=2, steps=5, world=1, device=None, ctl
     model.eval()
     total = statistics.mean(fwd) + statistics.mean(bwd) + statistics.mean(red) + statistics.mean(adam)
     out = {"forward_ms": statistics.mean(fwd), "backward_ms": statistics.mean(bwd),
-           "grad_allreduce_ms": statistics.mean(red) if world > 1 else None, "optimizer_ms": statistics.mean(adam),
+           "grad_allreduce_ms": statistics.mean(red) if do_exchange else None, "optimizer_ms": statistics.mean(adam),
            "ms_per_step": total, "node_steps_per_s": world * w["batch"] * 24 * w["nodes"] / (total * 1e-3),
            "steps": steps, "loss_first": losses[0], "loss_last": losses[-1],
            "note": "training step through the plugin surface, rank 0's clock: HIP forward that keeps activations "
                    "(incl. the prepare after every weight update) + HIP backward behind torch autograd "
                    "(+ one flat-bucket gradient all-reduce when n_gpus > 1) + torch Adam; dropout p=0.1 on"}
-    if world > 1:
+    if do_exchange:
         out["grad_bucket_mb"] = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4 / 1e6
         out["grad_bucket_is_one_buffer"] = bool(exchange["bucket"] and exchange["leftover_elems"] == 0)
         out["grad_exchange"] = exchange
@@ -405,7 +413,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1
+    # MATGCN_BENCH_FORCE_DIST=1 (rehearsal, never set by the driver): take the multi-rank branch with ONE rank too, so
+    # that a one-GPU box runs it over the real backend (nccl = RCCL): tools/rehearse_rccl_1rank.sh
+    distributed = world > 1 or os.environ.get("MATGCN_BENCH_FORCE_DIST") == "1"
     # rehearsal knobs (a 2-rank dry run of the multi-rank code path on a ONE-GPU box): every rank on device 0 and
     # gloo instead of RCCL; never set by the driver
     if os.environ.get("MATGCN_BENCH_ONE_DEVICE") == "1":
@@ -653,7 +663,7 @@ def main():
             result["gpu_over_cpu"] = value / best_cpu       # against the FASTER of the two CPU runs
             result["gpu_over_cpu_basis"] = "the faster CPU run: %d threads" % (
                 base["cores"] if best_cpu == base["value"] else 8)
-        if world == 1 and not args.no_train_step:
+        if world == 1 and not distributed and not args.no_train_step:
             cpu_train = None
             if not args.no_cpu_baseline and args.workload != "synth4096":
                 cpu_train = cpu_train_baseline(w, x_np, y_np, dict(model.named_parameters()), df)   # before the weights move
@@ -686,7 +696,7 @@ def main():
     if distributed and not args.no_train_step:
         # every rank takes part (the gradient all-reduce is a collective); rank 0 reports
         try:
-            ts = train_step_times(model, batch, w, world=world, device=device, ctl=ctl_group)
+            ts = train_step_times(model, batch, w, world=world, device=device, ctl=ctl_group, do_exchange=True)
         except Exception as exc:   # noqa: BLE001 - the headline line must survive a failure of the optional section
             ts = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0:

@@ -227,3 +227,57 @@ def test_two_rank_training_steps_on_one_gpu(tmp_path):
     world = 2
     mp.spawn(_gpu_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("gpu_dp_ok%d" % r)).exists() for r in range(world))
+
+
+def _rccl_one_rank_worker(rank, world, port, out_dir):
+    """the same data-parallel step over the backend the product runs on - nccl = RCCL - with the one rank a one-GPU box
+    allows: device-side layout vote, the flat bucket and the flat copy through RCCL all-reduces, the replica checksum on
+    the GPU.  With one rank the mean is the identity: gradients must come back bit-identical."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import Case
+    from multistgraph_amd.model import MultiATGCN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        for name, has_bucket, has_rest in (("tiny_multi_uni_c2_static", True, True), ("hid32_multi_uni_c2", False, True),
+                                           ("tiny_multi_uni_c2", True, False)):
+            c = Case(name)
+            torch.manual_seed(11)
+            model = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            x = torch.from_numpy(c.x).to(dev)
+            y = torch.from_numpy(c.y).to(dev)
+            for _ in range(2):
+                opt.zero_grad()
+                loss = model.calculate_loss({"X": x, "y": y})
+                loss.backward()
+                before = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+                info = sh.allreduce_model_grads_(model)
+                assert info["bucket"] == has_bucket and (info["leftover_elems"] > 0) == has_rest, (name, info)
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        assert torch.equal(p.grad, before[k]), (name, k)
+                opt.step()
+                assert sh.replicas_in_sync(model.parameters(), device=dev), name
+        # the bench's own aggregate over RCCL: barrier + MAX over ranks of the elapsed time, SUM of the units
+        total, slowest = sh.job_throughput(1000.0, 0.5, device=dev)
+        assert abs(total - 2000.0) < 1e-6 and abs(slowest - 0.5) < 1e-9
+        g = sh.gather_predictions(torch.arange(6, dtype=torch.float32, device=dev).reshape(2, 3), 2)
+        assert g.shape == (2, 3)
+        open(os.path.join(out_dir, "rccl_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gradient_exchange_over_rccl_with_the_one_rank_a_box_has(tmp_path):
+    """backend "nccl" (= RCCL) on the GPU: what a one-GPU box can exercise of the N > 1 path - process-group set-up on the
+    device, the layout vote and both gradient all-reduces as RCCL collectives on GPU tensors, the checksum on the GPU"""
+    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "rccl_ok0").exists()
