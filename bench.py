@@ -506,9 +506,9 @@ def main():
         notes = {1: "matgcn_set_mix_precision(1): the graph mixes round their operands (support stack, state rows) to "
                     "bf16 and run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; state, node-wise contractions, "
                     "inputs and outputs stay fp32",
-                 2: "matgcn_set_mix_precision(2): additionally the node-wise contractions of the recurrent step stream a "
-                    "bf16 copy of the node-adaptive weights (made once per forward, inside this time) and round their "
-                    "rows to bf16 on the way into LDS; fp32 accumulation, fp32 state / PX / residual cell"}
+                 2: "matgcn_set_mix_precision(2): additionally the node-wise contractions of the recurrent step and of the "
+                    "hoisted x part stream a bf16 copy of the node-adaptive weights (made once per forward, inside this "
+                    "time) and round their rows to bf16 on the way into LDS; fp32 accumulation, fp32 state / residual cell"}
         with torch.no_grad():
             exact = model.predict(batch).clone()
         bf16_variant = {"tolerance": 5e-3, "note": "reported beside the f32 headline, never as `value`"}

@@ -378,10 +378,11 @@ int matgcn_set_batch_split(int parts);
  * matgcn_set_mix_precision(1): the graph mixes of matgcn_forward / matgcn_forward_series round their operands - the
  * support stack and the state rows - to bf16 on the way into LDS and run on v_mfma_f32_16x16x16_bf16 with fp32
  * accumulation; inputs, outputs, the recurrent state, the node-wise contractions and everything in memory stay fp32.
- * matgcn_set_mix_precision(2): additionally the node-wise contractions of the recurrent step (MultiATGCN.py:108) take
- * bf16 operands: the node-adaptive weights are streamed from a bf16 copy of their fragment stream (made once per
- * forward in the workspace - half the bytes of the largest stream of a step), the rows [s | mix(s)] are rounded on
- * their way into LDS, fp32 accumulation; the state, the hoisted x part, the residual cell and every epilogue stay fp32.
+ * matgcn_set_mix_precision(2): additionally the node-wise contractions of the recurrent step (MultiATGCN.py:108) and,
+ * since round 4, of the hoisted x part of layers >= 1 take bf16 operands: the node-adaptive weights are streamed from a
+ * bf16 copy of their fragment streams (made once per forward in the workspace - half the bytes of the largest stream of
+ * a step), the rows [s | mix(s)] / [x | mix(x)] are rounded on their way into LDS, fp32 accumulation; the state, the
+ * layer-0 x part, the residual cell and every epilogue stay fp32.
  * Both are NARROWER than the reference's fp32 arithmetic: measured max-normalised deviation from the fp32 path <= 3e-3
  * (mode 1) at N = 403 (tests/test_hip_parity.py::test_bf16_mix_variant holds both modes to 5e-3).  matgcn_prepare, the
  * training entry points and the unit entry points always use fp32 operands.  Returns the previous setting; 0 (default)

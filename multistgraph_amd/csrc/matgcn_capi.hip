@@ -44,6 +44,7 @@ struct Plan {
   long oWg[MATGCN_MAX_LAYERS], oWu[MATGCN_MAX_LAYERS], oWx[MATGCN_MAX_LAYERS], oBx[MATGCN_MAX_LAYERS];
   long wgFloats[MATGCN_MAX_LAYERS], wuFloats[MATGCN_MAX_LAYERS];   // floats of the two recurrent weight streams
   long oW16g[MATGCN_MAX_LAYERS], oW16u[MATGCN_MAX_LAYERS];         // workspace: their bf16 copies (precision mode 2)
+  long oW16x[MATGCN_MAX_LAYERS];                                   // and of the hoisted x part's stream (layers >= 1)
   long oRg[MATGCN_MAX_LAYERS], oRu[MATGCN_MAX_LAYERS], oHead;
   long wxStride;
   int Cl[MATGCN_MAX_LAYERS], Cpad[MATGCN_MAX_LAYERS], nGx[MATGCN_MAX_LAYERS];
@@ -167,6 +168,7 @@ int make_plan(const matgcn_dims* D, Plan* P) {
   for (int l = 0; l < P->L; ++l) {
     P->oW16g[l] = take((P->wgFloats[l] + 1) / 2);   // bf16: two values per float slot
     P->oW16u[l] = take((P->wuFloats[l] + 1) / 2);
+    P->oW16x[l] = (l > 0 && !P->gcnOff) ? take(((long)P->N * P->wxStride + 1) / 2) : 0;
   }
   P->workspaceFloatsBf16 = o;
   return MATGCN_OK;
@@ -626,9 +628,12 @@ int node_kernels_ready(int ldsBytes) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, false, 32>), at, UPDATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gate16<true, 32>), at, GATE_LDS));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update16<1, true, 32>), at, UPDATE_SAVE_LDS));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<4>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<2>), at, ldsBytes));
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<1>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<4, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<2, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<1, false>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<4, true>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<2, true>), at, ldsBytes));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px16<1, true>), at, ldsBytes));
   ready = ldsBytes;
   return MATGCN_OK;
 }
@@ -679,9 +684,18 @@ int hoist_x(const Ctx& c, int l, const float* xin, int t0, int nt, hipStream_t s
   a.steps = nt; a.N = P.N; a.Np = P.Np; a.Ks = P.Ks; a.B = P.B;
   ProfScope prof(MATGCN_PROF_PX, s);
   const dim3 grid((unsigned)(rup(P.N, 8) * nt * P.RB));
-  if (P.B <= 16) hipLaunchKernelGGL(k_px16<1>, grid, dim3(512), P.nodeLds, s, a);         // row tiles that hold batch rows
-  else if (P.B <= 32) hipLaunchKernelGGL(k_px16<2>, grid, dim3(512), P.nodeLds, s, a);
-  else hipLaunchKernelGGL(k_px16<4>, grid, dim3(512), P.nodeLds, s, a);
+  // precision mode 2 (inference forwards only): the bf16 copy of the stream, A rows rounded on their way into LDS
+  const bool bf = g_node_bf16_now && !c.train;
+  if (bf) a.w = c.ws + P.oW16x[l];
+#define PX16_LAUNCH(NRT)                                                                                   \
+  do {                                                                                                     \
+    if (bf) hipLaunchKernelGGL((k_px16<NRT, true>), grid, dim3(512), P.nodeLds, s, a);                     \
+    else hipLaunchKernelGGL((k_px16<NRT, false>), grid, dim3(512), P.nodeLds, s, a);                       \
+  } while (0)
+  if (P.B <= 16) PX16_LAUNCH(1);         // row tiles that hold batch rows
+  else if (P.B <= 32) PX16_LAUNCH(2);
+  else PX16_LAUNCH(4);
+#undef PX16_LAUNCH
   return launch_ok();
 }
 
@@ -849,6 +863,12 @@ int encoder_chains(const Ctx& c, const float* x0p, const float* h0User, float* f
       hipLaunchKernelGGL(k_stream_to_bf16, dim3(blocks_for(ou)), dim3(256), 0, c.s, c.prep + P.oWu[l],
                          reinterpret_cast<unsigned int*>(c.ws + P.oW16u[l]), ou);
       CHECK_LAUNCH();
+      if (l > 0) {   // the hoisted x part's stream (k_px16<.., true>)
+        const size_t ox = (size_t)((long)P.N * P.wxStride / 8);
+        hipLaunchKernelGGL(k_stream_to_bf16, dim3(blocks_for(ox)), dim3(256), 0, c.s, c.prep + P.oWx[l],
+                           reinterpret_cast<unsigned int*>(c.ws + P.oW16x[l]), ox);
+        CHECK_LAUNCH();
+      }
     }
   }
   if (multi) {

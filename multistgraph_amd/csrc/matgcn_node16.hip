@@ -565,8 +565,9 @@ __device__ __forceinline__ float4 a_frag(const float* Hs, const float* Gs, int K
 
 // NRT: 16-row tiles of the 64-row block that hold batch rows (4; 2 / 1 for batches of at most 32 / 16 rows - the reference
 // ships batch_size 16, where three of the four row tiles were padding: 64 us per launch at ANY batch size until round 4)
-template <int NRT>
+template <int NRT, bool BF = false>
 __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
+  typedef typename NodeOp<BF>::T Op;   // BF (precision mode 2): the bf16 copy of the weight stream, A rows rounded into LDS
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Hs = lds;
   float* Gs = lds + 64 * 64;
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
   const int nG = 4 * (1 + p.Ks);
   const bool two = w < 4;                       // this wave also owns column tile w + 8
-  const float4* wp0 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
-  const float4* wp1 = reinterpret_cast<const float4*>(p.w) + ((size_t)n * nG * 12 + min(w + 8, 11)) * 64 + lane;
+  const Op* wp0 = reinterpret_cast<const Op*>(p.w) + ((size_t)n * nG * 12 + w) * 64 + lane;
+  const Op* wp1 = reinterpret_cast<const Op*>(p.w) + ((size_t)n * nG * 12 + min(w + 8, 11)) * 64 + lane;
   Node16Args a;                                 // the staging helper speaks Node16Args: the B rows of step tl
   a.s = p.x + (size_t)tl * p.B * p.Np * 64;
   a.g = p.g + (size_t)tl * p.B * p.Ks * 64; a.gNodeStride = (long)p.steps * p.B * p.Ks * 64;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   // the first weight groups and the bias depend on nothing this kernel stages: requested BEFORE the A tile, they are in
   // flight while the tile's 64 KB go global -> registers -> LDS (round 4: no measurable gain, 69.6 us either way; a ring of
   // 6 groups instead of 4 is slower, 72 us: profiles/r04_small_batch_lab.log)
-  float4 wr0[PX16_RING], wr1[PX16_RING];
+  Op wr0[PX16_RING], wr1[PX16_RING];
 #pragma unroll
   for (int r = 0; r < PX16_RING; ++r) {
     wr0[r] = wp0[(size_t)min(r, nG - 1) * 12 * 64];
@@ -615,54 +616,63 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
   auto chunk = [&](const float* buf, int c) {
-    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const Op* tile = reinterpret_cast<const Op*>(buf);
 #pragma unroll
     for (int gl = 0; gl < 4; ++gl) {
       const int g = 4 * c + gl;
-      const float4 wv0 = wr0[gl], wv1 = wr1[gl];
+      const Op wv0 = wr0[gl], wv1 = wr1[gl];
       wr0[gl] = wp0[(size_t)min(g + 4, nG - 1) * 12 * 64];
       wr1[gl] = wp1[(size_t)min(g + 4, nG - 1) * 12 * 64];
-      float4 av[NRT];
+      Op av[NRT];
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) av[rt] = tile[(rt * 16 + j) * 16 + ((4 * gl + kq) ^ j)];
+      if constexpr (BF) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16BF(as_bf16x4(av[rt]), as_bf16x4(wv0), acc0[rt]);
+        if (two) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16BF(as_bf16x4(av[rt]), as_bf16x4(wv1), acc1[rt]);
+        }
+      } else {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].x, wv0.x, acc0[rt]);
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
-      if (two) {
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].y, wv0.y, acc0[rt]);
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].z, wv0.z, acc0[rt]);
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
+        for (int rt = 0; rt < NRT; ++rt) acc0[rt] = MFMA16(av[rt].w, wv0.w, acc0[rt]);
+        if (two) {
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].x, wv1.x, acc1[rt]);
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].y, wv1.y, acc1[rt]);
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].z, wv1.z, acc1[rt]);
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) acc1[rt] = MFMA16(av[rt].w, wv1.w, acc1[rt]);
+        }
       }
     }
   };
-  chunk_store<64>(Hs, cs, hS);
+  chunk_store<64, BF>(Hs, cs, hS);
   __syncthreads();
   if (Ks > 0) {
     chunk(Hs, 0);
-    chunk_store<64>(Gb, cs, st[1]);
-    if (Ks > 1) chunk_store<64>(Gb + CH, cs, st[0]);
+    chunk_store<64, BF>(Gb, cs, st[1]);
+    if (Ks > 1) chunk_store<64, BF>(Gb + CH, cs, st[0]);
     chunk_load<64>(cs, Ks, 3, st[1]);
     chunk_load<64>(cs, Ks, 4, st[0]);
     __syncthreads();
     for (int c = 1; c < Ks; c += 2) {
       chunk(Gb, c);
       __syncthreads();
-      if (c + 2 <= Ks) chunk_store<64>(Gb, cs, st[1]);
+      if (c + 2 <= Ks) chunk_store<64, BF>(Gb, cs, st[1]);
       chunk_load<64>(cs, Ks, c + 4, st[1]);
       if (c + 1 < Ks) {
         chunk(Gb + CH, c + 1);
         __syncthreads();
-        if (c + 3 <= Ks) chunk_store<64>(Gb + CH, cs, st[0]);
+        if (c + 3 <= Ks) chunk_store<64, BF>(Gb + CH, cs, st[0]);
         chunk_load<64>(cs, Ks, c + 5, st[0]);
       }
     }
@@ -670,6 +680,7 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   if (Ks & 1) chunk(Gb, Ks);
   else chunk(Ks > 0 ? Gb + CH : Hs, Ks);
 #else
+  static_assert(!BF, "the bf16 form exists for the chunked A tile only");
   stage_node_tile(a, n, rowBase, Hs, Gs);
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) { acc0[rt] = f32x4{b0, b0, b0, b0}; acc1[rt] = f32x4{b1, b1, b1, b1}; }
