@@ -811,8 +811,17 @@ __device__ __forceinline__ float4 ld4(const float* p, size_t idx) { return *rein
 __device__ __forceinline__ float4 ld4b(const float* p, unsigned byteOfs) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + byteOfs);
 }
+#ifndef CHAIN_STORE_WT
+#define CHAIN_STORE_WT 1   // the fused chain kernels' outputs are the next chain kernel's inputs: written through (sc1) like the
+#endif                     // forward's step outputs, instead of dirty L2 lines flushed at the end of the kernel
 __device__ __forceinline__ void st4b(float* p, unsigned byteOfs, const float4& v) {
+#if CHAIN_STORE_WT
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7ffffff0, 0x00020000);   // p is wave-uniform (a kernel argument)
+  const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)byteOfs, 0, 16);            // aux 16 = sc1
+#else
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(p) + byteOfs) = v;
+#endif
 }
 __device__ __forceinline__ float get4(const float4& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : x == 2 ? v.z : v.w; }
 

@@ -46,8 +46,14 @@
 #ifndef NODE_XT_LATE
 #define NODE_XT_LATE 1              // k_update16: request the residual cell's x_t rows before the last K chunk
 #endif
+#ifndef NODE_SAVE_WT
+#define NODE_SAVE_WT 1    // the activations forward_train saves leave through write-through (sc1) stores like the outputs
+#endif
 #ifndef PX16_RING
 #define PX16_RING 4        // k_px16: two rings (two column tiles per wave)
+#endif
+#ifndef PX16_OUT_WT
+#define PX16_OUT_WT 1      // k_px16 writes PX through (sc1)
 #endif
 #ifndef PX16_PIPELINE
 #define PX16_PIPELINE 1    // k_px16 stages its A tile in K chunks under the MFMAs (0: whole tile first, the round-3 form)
@@ -147,6 +153,16 @@ __device__ __forceinline__ void store_wt16(float* base, size_t off, const float4
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
   const u32x4_n16 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(bits, rsrc, (int)(off * 4), 0, 16);   // aux 16 = sc1
+}
+
+// a saved activation (forward_train): nothing reads it before the backward, milliseconds later.  Written through as well
+// (NODE_SAVE_WT): a plain store leaves a dirty line in this XCD's L2 for the flush at the end of the kernel
+__device__ __forceinline__ void save16(float* base, size_t off, const float4& v) {
+#if NODE_SAVE_WT
+  store_wt16(base, off, v);
+#else
+  *reinterpret_cast<float4*>(base + off) = v;
+#endif
 }
 
 // position (in floats) of element (row, col) of a swizzled [.][16*blocks slots] tile with `spr` slots per row
@@ -500,8 +516,8 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES_GATE : NODE_MIN_WA
     }
     store_wt16(a.zh, ((size_t)b * a.Np + n) * 64 + q * 4, v);
     if constexpr (SAVE) {
-      *reinterpret_cast<float4*>(a.svZ + ((size_t)b * a.Np + n) * 64 + q * 4) = z;
-      *reinterpret_cast<float4*>(a.svR + ((size_t)b * a.Np + n) * 64 + q * 4) = *reinterpret_cast<const float4*>(&Rt[at]);
+      save16(a.svZ, ((size_t)b * a.Np + n) * 64 + q * 4, z);
+      save16(a.svR, ((size_t)b * a.Np + n) * 64 + q * 4, *reinterpret_cast<const float4*>(&Rt[at]));
     }
   }
   NODE_STAMP(17);  // stores issued
@@ -719,12 +735,25 @@ __global__ __launch_bounds__(512, 4) void k_px16(Px16Args p) {
   }
 #endif
   // the accumulators leave as they are: one 1 KB wave row per (column tile, row tile)
+#if PX16_OUT_WT
+  // written through (sc1) like every other producer -> consumer buffer of the step kernels: the 39 MB a chunk's launch
+  // produces leave the L2s while it runs, not as dirty lines at its end (this (node, step, row block)'s 48 KB block is the
+  // wave-uniform base, so the lane offsets stay small at any N)
+  float* pxb = p.pxOut + (((size_t)tl * p.N + n) * RB + rb) * NODE_PX_BLOCK;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    store_wt16(pxb, (((size_t)w * 4 + rt) * 64 + lane) * 4, make_float4(acc0[rt][0], acc0[rt][1], acc0[rt][2], acc0[rt][3]));
+    if (two)
+      store_wt16(pxb, (((size_t)(w + 8) * 4 + rt) * 64 + lane) * 4, make_float4(acc1[rt][0], acc1[rt][1], acc1[rt][2], acc1[rt][3]));
+  }
+#else
   float4* dst = reinterpret_cast<float4*>(p.pxOut) + (((size_t)tl * p.N + n) * RB + rb) * (NODE_PX_BLOCK / 4) + lane;
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) {
     dst[((size_t)w * 4 + rt) * 64] = make_float4(acc0[rt][0], acc0[rt][1], acc0[rt][2], acc0[rt][3]);
     if (two) dst[((size_t)(w + 8) * 4 + rt) * 64] = make_float4(acc1[rt][0], acc1[rt][1], acc1[rt][2], acc1[rt][3]);
   }
+#endif
 }
 
 // ---- update AGCN + tanh + GRU blend, fused with the residual GRU cell and the per-step blend ------------------
@@ -878,8 +907,7 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     for (int it = 0; it < NS; ++it) {
       const int lb = srow + 32 * it, b = rowBase + lb;
       if (b < a.rows)
-        *reinterpret_cast<float4*>(a.svHC + ((size_t)b * a.Np + n) * 64 + sq * 4) =
-            *reinterpret_cast<const float4*>(&SV[(lb * 16 + (sq ^ (lb & 15))) * 4]);
+        save16(a.svHC, ((size_t)b * a.Np + n) * 64 + sq * 4, *reinterpret_cast<const float4*>(&SV[(lb * 16 + (sq ^ (lb & 15))) * 4]));
     }
   }
   // GEMM 1: zr2 = sigmoid([x|h'] Wg + bg): wave w = column tile w (of 8), all row tiles
@@ -1017,13 +1045,13 @@ __global__ __launch_bounds__(512, ROWS == 64 ? NODE_MIN_WAVES : NODE_MIN_WAVES_3
     if (a.seq) store_wt16(a.seq, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4, v);
     if constexpr (SAVE) {
       const size_t sat = ((size_t)b * a.Np + n) * 64 + sq * 4;
-      *reinterpret_cast<float4*>(a.svZ2 + sat) = *reinterpret_cast<const float4*>(&SV[at]);
-      *reinterpret_cast<float4*>(a.svR2 + sat) = *reinterpret_cast<const float4*>(&R2[at]);
-      *reinterpret_cast<float4*>(a.svHC2 + sat) = *reinterpret_cast<const float4*>(&HC2t[at]);
+      save16(a.svZ2, sat, *reinterpret_cast<const float4*>(&SV[at]));
+      save16(a.svR2, sat, *reinterpret_cast<const float4*>(&R2[at]));
+      save16(a.svHC2, sat, *reinterpret_cast<const float4*>(&HC2t[at]));
       if (a.seqDrop) {
         const float4 m = *reinterpret_cast<const float4*>(a.dropMask + (size_t)b * a.dropRowStride + (size_t)n * 64 + sq * 4);
-        *reinterpret_cast<float4*>(a.seqDrop + (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4) =
-            make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+        save16(a.seqDrop, (size_t)b * a.seqRowStride + (size_t)n * 64 + sq * 4,
+               make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w));
       }
     }
   }
