@@ -44,8 +44,11 @@ import time
 # HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The path runs its layer chains, the hoisted
 # x parts and the backward's side work on streams of its own; once an RCCL communicator has taken queues as well, two chains
 # share one and serialise: forward 8.0 instead of 6.8 ms under an initialised process group, 6.8 with 8 queues (10 and more
-# cost the training step 20 %: profiles/r04_rccl_queues_lab.log).  Must be in the environment before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# cost the training step 20 %: profiles/r04_rccl_queues_lab.log).  Only for the multi-rank launch: WITHOUT a process group 4
+# and 8 are level on synchronised steps, but three of eight free-running training loops ran 20-37 % slower at 8, none at 4.
+# Must be in the environment before the HIP runtime starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MATGCN_BENCH_FORCE_DIST") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -654,19 +657,15 @@ def main():
                 "value_rank0": w["batch"] * 24 * w["nodes"] * args.steps / frozen_elapsed,
                 "note": "same steps with the parameter-only work (matgcn_prepare) cached between forwards; "
                         "rank 0's own rate, not part of `value`"}
-        if world == 1 and not args.no_cpu_baseline and args.workload != "synth4096":   # (hours of CPU time at N=4096)
-            base, pred_cpu = cpu_baseline(w, seed, x_np, dict(model.named_parameters()), df, pred)
-            result["cpu_baseline"] = base
-            result["mae_at_12_cpu"] = float(masked_mae(pred_cpu[:, min(12, w["out"]) - 1],
-                                                       torch.from_numpy(y_np)[:, min(12, w["out"]) - 1, :, 0:1]).item())
-            best_cpu = max(base["value"], (base.get("at_8_threads") or {}).get("value", 0.0))
-            result["gpu_over_cpu"] = value / best_cpu       # against the FASTER of the two CPU runs
-            result["gpu_over_cpu_basis"] = "the faster CPU run: %d threads" % (
-                base["cores"] if best_cpu == base["value"] else 8)
+        # Order (round 4): every GPU side line first, on a quiet host, the CPU baselines LAST.  The oracle's 128 torch
+        # threads keep spinning for a while after their last parallel region; the training step and the B = 16 side line
+        # that used to follow them measured that (host enqueue 6.1 instead of 3.6 ms per B = 16 step, the training forward
+        # 0.3-0.7 ms slower than tools/host_enqueue_time.py on the same box).  The CPU runs take the parameters as they
+        # were for the timed forwards: a snapshot from before the training steps move them.
+        want_cpu = world == 1 and not args.no_cpu_baseline and args.workload != "synth4096"   # (hours of CPU time at N=4096)
+        snapshot = {k: v.detach().cpu().clone() for k, v in model.named_parameters()} if want_cpu else None
+        pred_fp32 = pred.detach().cpu().clone() if want_cpu else None   # (the output buffer is reused by later forwards)
         if world == 1 and not distributed and not args.no_train_step:
-            cpu_train = None
-            if not args.no_cpu_baseline and args.workload != "synth4096":
-                cpu_train = cpu_train_baseline(w, x_np, y_np, dict(model.named_parameters()), df)   # before the weights move
             ts = train_step_times(model, batch, w)
             # every forward GEMM has two backward GEMMs (input gradient, weight gradient): the backward executes ~2x the
             # forward's EXECUTED FLOPs (dense supports only, shared mixes) - not 2x the SURVEY formula
@@ -679,9 +678,6 @@ def main():
                                          "bench.backward_executed_flops (every product once, unpadded; only the learned "
                                          "support has an adjacency-gradient GEMM) / backward time: a utilisation of the "
                                          "dense fp32 MFMA peak")
-            if cpu_train is not None:
-                ts["cpu_baseline"] = cpu_train
-                ts["gpu_over_cpu"] = ts["node_steps_per_s"] / cpu_train["value"]
             result["train_step"] = ts
         if world == 1 and not args.no_batch16 and args.workload != "synth4096" and w["batch"] != 16:
             # the reference's shipped batch size (MultiATGCN.json:12) on this workload's graph - and on the other headline
@@ -693,6 +689,19 @@ def main():
                 result["batch16"] = b16
             except Exception as exc:   # noqa: BLE001 - a side line must not take the headline with it
                 result["batch16"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if want_cpu:
+            base, pred_cpu = cpu_baseline(w, seed, x_np, snapshot, df, pred_fp32)
+            result["cpu_baseline"] = base
+            result["mae_at_12_cpu"] = float(masked_mae(pred_cpu[:, min(12, w["out"]) - 1],
+                                                       torch.from_numpy(y_np)[:, min(12, w["out"]) - 1, :, 0:1]).item())
+            best_cpu = max(base["value"], (base.get("at_8_threads") or {}).get("value", 0.0))
+            result["gpu_over_cpu"] = value / best_cpu       # against the FASTER of the two CPU runs
+            result["gpu_over_cpu_basis"] = "the faster CPU run: %d threads" % (
+                base["cores"] if best_cpu == base["value"] else 8)
+            if "train_step" in result and "error" not in result["train_step"]:
+                cpu_train = cpu_train_baseline(w, x_np, y_np, snapshot, df)
+                result["train_step"]["cpu_baseline"] = cpu_train
+                result["train_step"]["gpu_over_cpu"] = result["train_step"]["node_steps_per_s"] / cpu_train["value"]
     if distributed and not args.no_train_step:
         # every rank takes part (the gradient all-reduce is a collective); rank 0 reports
         try:

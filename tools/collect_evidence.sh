@@ -7,6 +7,7 @@ TAG=$1; RD=$2; LB=$3; O=gpurun_out/$TAG; P=profiles
 [ -f $O/bench_dc237.json ] && cp $O/bench_dc237.json $P/${RD}_${LB}_bench_dc237.json
 [ -f $O/bench_synth4096.json ] && cp $O/bench_synth4096.json $P/${RD}_${LB}_bench_synth4096.json
 [ -f $O/rehearsal_2rank_gloo_one_gpu.json ] && cp $O/rehearsal_2rank_gloo_one_gpu.json $P/${RD}_${LB}_rehearsal_2rank_gloo_one_gpu.json
+[ -f $O/rehearsal_1rank_rccl.json ] && cp $O/rehearsal_1rank_rccl.json $P/${RD}_${LB}_rehearsal_1rank_rccl.json
 [ -f $O/pytest.log ] && tail -4 $O/pytest.log > $P/${RD}_${LB}_pytest_gpu_tail.txt
 [ -f $O/smoke.log ] && cp $O/smoke.log $P/${RD}_${LB}_smoke.log
 [ -f $O/host_enqueue.log ] && cp $O/host_enqueue.log $P/${RD}_${LB}_host_enqueue.log

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The round's evidence on one build, in two parts (each fits one gpurun call):
 #   final_run.sh tests  [tag]   full GPU suite, smoke, bench lines of the three single-GPU workloads (+ training lines),
-#                               host enqueue time, the 2-rank gloo rehearsal of bench.py's distributed branch
+#                               host enqueue time, the 2-rank gloo and 1-rank RCCL rehearsals of bench.py's distributed branch
+#   final_run.sh bench  [tag]   the same without the suite
 #   final_run.sh profile [tag]  rocprofv3 kernel stats (serial + default schedule, training step) and the PMC passes
 # Everything lands under gpurun_out/<tag>/ (and gpurun_out/prof_<tag>, pmc_train_<tag>); the summaries worth keeping are
 # copied into profiles/r<round>_* by hand afterwards.
@@ -10,9 +11,11 @@ PART=${1:-tests}
 TAG=${2:-final}
 O=gpurun_out/$TAG
 mkdir -p $O
-if [ "$PART" = "tests" ]; then
-  python -m pytest tests -q -m gpu > $O/pytest.log 2>&1
-  echo "pytest rc=$?"; tail -3 $O/pytest.log
+if [ "$PART" = "tests" ] || [ "$PART" = "bench" ]; then
+  if [ "$PART" = "tests" ]; then     # ("bench": the same without the suite - after a change of bench.py alone)
+    python -m pytest tests -q -m gpu > $O/pytest.log 2>&1
+    echo "pytest rc=$?"; tail -3 $O/pytest.log
+  fi
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
   echo "smoke rc=$?"; tail -2 $O/smoke.log
   python bench.py > $O/bench.json 2> $O/bench.err
@@ -25,6 +28,8 @@ if [ "$PART" = "tests" ]; then
   tail -2 $O/host_enqueue.log
   bash tools/rehearse_2rank.sh > $O/rehearse.log 2>&1
   echo "rehearse rc=$?"; cp gpurun_out/rehearse/bench_2rank.json $O/rehearsal_2rank_gloo_one_gpu.json 2>/dev/null
+  bash tools/rehearse_rccl_1rank.sh > $O/rehearse_rccl.log 2>&1
+  echo "rehearse rccl rc=$?"; cp gpurun_out/rehearse/bench_rccl_1rank.json $O/rehearsal_1rank_rccl.json 2>/dev/null
 else
   bash tools/profile_run.sh $TAG > $O/profile.log 2>&1
   echo "profile rc=$?"; cat gpurun_out/prof_$TAG/pmc_kernels.txt
