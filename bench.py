@@ -137,7 +137,9 @@ def step_kernel_models(n, npad, b, ks, h=64):
 
 
 # prefixes of the kernel names as rocprofv3 prints them (template arguments after these vary with the build)
-PMC_KERNEL_NAMES = {"k_mix": "k_mix<1>", "k_gate": "k_gate16<false", "k_update": "k_update16<1, false", "k_px": "k_px16"}
+# substrings of the profiler's kernel names (template arguments that were added later follow the ones matched here)
+PMC_KERNEL_NAMES = {"k_mix": "k_mix<1", "k_gate": "k_gate16<false", "k_update": "k_update16<1, false", "k_px": "k_px16<"}
+NODE_KERNEL_KEYS = {"k_gate": "k_gate16<false", "k_update": "k_update16<1, false", "k_px": "k_px16"}   # keys of roofline.node_kernels
 
 
 def load_pmc(build_id):
@@ -588,7 +590,7 @@ def main():
             if kind == "k_px":   # a launch covers a chunk of 1-4 steps: scale the per-step model by the average chunk
                 steps_per_launch = 24.0 * (spec.layers - 1) / (len(ms_list) / 2.0)
                 models[kind] = {k: v * steps_per_launch for k, v in models[kind].items()}
-            node_kernels[PMC_KERNEL_NAMES[kind]] = dict(
+            node_kernels[NODE_KERNEL_KEYS[kind]] = dict(
                 launches=len(ms_list), avg_launch_ms=t * 1e3, flops_per_launch=models[kind]["flops"],
                 algorithmic_bytes_per_launch=models[kind]["bytes"], achieved_tflops=models[kind]["flops"] / t / 1e12,
                 frac_mfma=models[kind]["flops"] / t / 1e12 / PEAK_MFMA_F32_TFLOPS,

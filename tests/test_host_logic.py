@@ -284,3 +284,20 @@ def test_bench_flop_models_are_consistent():
         assert 1.3 * fwd < bwd < 2.0 * fwd, (n, bwd / fwd)
     m = bench.step_kernel_models(403, 416, 64, 3)
     assert abs(m["k_mix"]["flops"] - 2 * 3 * 403 * 403 * 64 * 64) < 1
+
+
+def test_bench_finds_its_kernels_in_the_committed_pmc_summary():
+    """bench.py replays the PMC figures of profiles/r*_pmc_kernels.json by kernel NAME: every name it looks for must be in
+    the newest summary (round 4: a template argument added to k_mix silently turned the roofline kernel's traffic into null)"""
+    import glob
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_kernels.json")), reverse=True)
+    assert found, "no PMC summary committed"
+    names = list(json.load(open(found[0]))["kernels"])
+    for kind, needle in bench.PMC_KERNEL_NAMES.items():
+        hits = [n for n in names if needle in n]
+        assert hits, (kind, needle, names)
+        if kind == "k_mix":
+            assert all("bf16" not in n for n in hits), hits
