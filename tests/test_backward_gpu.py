@@ -455,6 +455,9 @@ def test_full_size_directional_derivative(lib_built):
 
 @pytest.mark.parametrize("n,b,layers,flags", [
     (16, 70, 2, {}), (32, 5, 2, {}), (21, 3, 1, {}), (21, 3, 3, {}), (16, 2, 4, {}), (21, 1, 2, {}),
+    # the shipped batch size and its double (MultiATGCN.json:12): 32-row node work items in the training forward, the steps of an
+    # x-part chunk in one k_px16 tile
+    (21, 16, 2, {}), (19, 32, 3, {}),
     (21, 2, 3, {"gcn_off": True}), (21, 2, 3, {"fnn_off": True}), (21, 2, 1, {"gcn_off": True, "fnn_off": True}),
     (19, 2, 3, {"cheb_order": 3}),
     # cheb_order = 1 (run_model_parameter.py:13): one weight entry over I + sum of the supports (MultiATGCN.py:94-108)

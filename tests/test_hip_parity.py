@@ -252,9 +252,10 @@ def test_encoder_nonzero_initial_state_vs_oracle(lib_built):
     assert max_norm_err(fin.cpu().numpy(), torch.stack(want_fin, 0).numpy()) <= E2E_TOL
 
 
-@pytest.mark.parametrize("batch", [1, 5, 64, 70])
+@pytest.mark.parametrize("batch", [1, 5, 16, 32, 48, 64, 70])
 def test_ragged_batches_vs_oracle(batch, lib_built):
-    # batch sizes around the 64-row tile of the node-wise contraction, N not a multiple of 16
+    # batch sizes around the 64-row tile of the node-wise contraction, N not a multiple of 16; 16 and 32: the steps of an x-part
+    # chunk share one tile (k_px16 merge), 32-row node work items
     from multistgraph_amd import synthetic as syn
     from oracle import matgcn_oracle as O
     c = Case("tiny_multi_uni_c2")
