@@ -41,15 +41,6 @@ import statistics
 import sys
 import time
 
-# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The path runs its layer chains, the hoisted
-# x parts and the backward's side work on streams of its own; once an RCCL communicator has taken queues as well, two chains
-# share one and serialise: forward 8.0 instead of 6.8 ms under an initialised process group, 6.8 with 8 queues (10 and more
-# cost the training step 20 %: profiles/r04_rccl_queues_lab.log).  Only for the multi-rank launch: WITHOUT a process group 4
-# and 8 are level on synchronised steps, but three of eight free-running training loops ran 20-37 % slower at 8, none at 4.
-# Must be in the environment before the HIP runtime starts.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MATGCN_BENCH_FORCE_DIST") == "1":
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -443,6 +434,11 @@ def main():
         mbuild.build(verbose=False)
     if distributed:
         dist.barrier()
+        # inside a process group the path keeps its streams in a hardware-queue pool of their own: the communicator's streams
+        # would otherwise push two of its chains onto one queue (forward 8.0 instead of 6.8 ms; sharding.use_own_stream_pool)
+        if os.environ.get("MATGCN_BENCH_SHARED_POOL") != "1":      # (lab switch: the default streams)
+            from multistgraph_amd import sharding as _sh
+            _sh.use_own_stream_pool()
 
     w = dict(WORKLOADS[args.workload])
     if args.batch:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MATGCN_ABI_VERSION 10
+#define MATGCN_ABI_VERSION 11
 
 typedef enum matgcn_status {
   MATGCN_OK = 0,
@@ -352,6 +352,20 @@ int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* d
  * matgcn_set_wavefront(2) is a lab switch (round 4, measured and rejected: 8.3 against 6.8 ms): the graph mixes of all
  * chains form one global order so that a mix only ever runs beside the other chain's node kernel; same results. */
 int matgcn_set_wavefront(int enabled);
+
+/* Hardware queues.  The HIP runtime maps the streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
+ * stream priority, round robin in creation order, and which of the library's streams share a queue decides how well the
+ * layers' chains overlap.  By default the library creates ordinary streams and runs the first chain on the caller's
+ * stream: the best measured for a single process - but the pool is shared with every other stream of the process, and an
+ * RCCL communicator created before the library's streams moves them onto each other's queues (forward 8.0 instead of
+ * 6.8 ms at the headline shape, identical kernel durations: profiles/r04_rccl_queues_lab.log).
+ * matgcn_set_stream_pool(1) - for data-parallel jobs - makes the library create its streams at the device's highest
+ * priority (a queue pool nothing else in the process uses) at chosen places of the round robin, and run
+ * matgcn_forward / _forward_series / _forward_train / _backward on a library stream forked from and joined back into the
+ * caller's: the same timings with and without a process group, about 1 % behind the default without one.  Must be called
+ * before the first of those entry points creates the streams (MATGCN_ERR_BAD_ARG afterwards, unless the mode asked for is
+ * the one in use).  Results are bit-identical in both modes. */
+int matgcn_set_stream_pool(int own);
 
 /* Lazy prepare.  By default `prepared` is complete, in stream order, when matgcn_prepare returns.  With
  * matgcn_set_lazy_prepare(1) matgcn_prepare returns while the node-adaptive weight streams (most of its work) are still

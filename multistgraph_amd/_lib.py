@@ -11,7 +11,7 @@ import os
 
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_LAYERS = 4
 MAX_HEADS = 8
 MAX_EXT = 16
@@ -111,6 +111,7 @@ _SIGNATURES = {
                                   C.POINTER(Params), _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "matgcn_debug_gemm": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_float, C.c_float, _P]),
     "matgcn_set_wavefront": (C.c_int, [C.c_int]),
+    "matgcn_set_stream_pool": (C.c_int, [C.c_int]),
     "matgcn_set_mix_precision": (C.c_int, [C.c_int]),
     "matgcn_set_batch_split": (C.c_int, [C.c_int]),
     "matgcn_set_lazy_prepare": (C.c_int, [C.c_int]),

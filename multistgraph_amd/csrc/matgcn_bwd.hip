@@ -1427,17 +1427,26 @@ static int forward_train_impl(const matgcn_dims* dims, const matgcn_params* para
 
 // a failure between a fork onto the library streams and their join (side stream of the plain operands, the layers'
 // chains) joins them into the caller's stream before the error code is returned (join_library_streams)
-int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                         const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
-                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
+static int forward_train_entry(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                               const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
+                               size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
   JOINED(forward_train_impl(dims, params, prepared, X, src, h0, drop_mask, out, workspace, workspace_bytes, train,
                             train_bytes, stream), stream);
 }
 
-int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                    const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
-                    const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
-                    size_t train_bytes, void* stream) {
+int matgcn_forward_train(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                         const matgcn_series* src, const float* h0, const float* drop_mask, float* out, void* workspace,
+                         size_t workspace_bytes, void* train, size_t train_bytes, void* stream) {
+  return on_main_stream(stream, [&](void* s) {
+    return forward_train_entry(dims, params, prepared, X, src, h0, drop_mask, out, workspace, workspace_bytes, train,
+                               train_bytes, s);
+  });
+}
+
+static int backward_entry(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                          const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
+                          const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
+                          size_t train_bytes, void* stream) {
   if (!prepared || (!X && !src) || !d_out || !grads || !train) return MATGCN_ERR_NULL;
   if (src) RETURN_IF(check_series(dims, src->series, src->series_steps, src->label_start, src->rel_steps));
   Bwd b;
@@ -1448,6 +1457,16 @@ int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const 
   b.X = X; b.dropMask = drop_mask; b.g = grads; b.tr = (float*)train;
   b.hasH0 = h0 != nullptr; b.dH0 = d_h0; b.src = src;
   JOINED(backward_impl(b, d_out), stream);
+}
+
+int matgcn_backward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                    const matgcn_series* src, const float* h0, const float* drop_mask, const float* d_out,
+                    const matgcn_grads* grads, float* d_h0, void* workspace, size_t workspace_bytes, void* train,
+                    size_t train_bytes, void* stream) {
+  return on_main_stream(stream, [&](void* s) {
+    return backward_entry(dims, params, prepared, X, src, h0, drop_mask, d_out, grads, d_h0, workspace, workspace_bytes,
+                          train, train_bytes, s);
+  });
 }
 
 int matgcn_debug_gemm(const float* A, const float* B, float* C, const int64_t* desc, float alpha, float beta,

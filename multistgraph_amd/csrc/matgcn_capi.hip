@@ -322,8 +322,11 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 // streams, tied together by events.  While one chain sits in a memory-bound phase (weight stream of a node
 // kernel) the other can own the matrix cores (graph mix), and the tails of one kernel fill with the other's
 // workgroups.  Streams and events are created once, on first use; no call creates or destroys them afterwards.
+int g_stream_pool = 0;        // matgcn_set_stream_pool: 1 = library streams in a hardware-queue pool of their own
 struct Wavefront {
   bool ready = false;
+  hipStream_t main;                                // what the hot entry points use INSTEAD of the caller's stream (on_main_stream)
+  hipEvent_t mainFork, mainJoin;
   hipStream_t chain[MATGCN_MAX_LAYERS];            // [0] unused: layer 0 runs on the caller's stream
   hipStream_t xpart[MATGCN_MAX_LAYERS];
   hipEvent_t fork, done[MATGCN_MAX_LAYERS];
@@ -338,7 +341,7 @@ struct Wavefront {
   hipEvent_t xdone[MATGCN_MAX_LAYERS][MAX_STEPS];  // x-part chunk starting at step t of layer l is in PX
   hipEvent_t mixed[MATGCN_MAX_LAYERS][MAX_STEPS];  // layer l has mixed h_{t-1} (phase 0 of its step t)
   hipEvent_t mixz[MATGCN_MAX_LAYERS][MAX_STEPS];   // layer l has mixed z*h (phase 2 of its step t): the mix token's second stop
-  hipEvent_t bail[2 * MATGCN_MAX_LAYERS + 3];      // error exits: one per library stream (join_library_streams)
+  hipEvent_t bail[2 * MATGCN_MAX_LAYERS + 4];      // error exits: one per library stream (join_library_streams)
 };
 // one set per device ordinal: a HIP stream / event belongs to the device that was current when it was created, so a
 // process that drives several GPUs (or the rehearsal runs that put two ranks on one box) must not share them.
@@ -430,19 +433,59 @@ int split_ready() {
 
 int wavefront_ready() {
   if (g_wf.ready) return MATGCN_OK;
-  for (int l = 1; l < MATGCN_MAX_LAYERS; ++l) {
-    HIP_OK(hipStreamCreateWithFlags(&g_wf.chain[l], hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&g_wf.xpart[l], hipStreamNonBlocking));
+  // The runtime hands hardware queues (GPU_MAX_HW_QUEUES of them, default 4) to the streams of a process round robin in
+  // creation order, from one pool per stream PRIORITY.  Which of the library's streams share a queue decides how well the
+  // chains overlap (round 4, profiles/r04_rccl_queues_lab.log): two chains on one queue serialise - forward 8.0 instead of
+  // 6.8 ms - while the main chain sharing one with the x-part stream is the GOOD arrangement.
+  //  * default (matgcn_set_stream_pool(0)): default-priority streams in the order below, chain 0 on the caller's stream.
+  //    Measured best for a single process; but the pool is shared with every other stream of the process, so an RCCL
+  //    communicator created first moves everything to other queues (the 8.0 ms above).
+  //  * own pool (matgcn_set_stream_pool(1), for data-parallel jobs): every library stream at the device's highest priority
+  //    - a pool no other stream of the process touches - and the hot entry points on the library's `main` stream instead of
+  //    the caller's (on_main_stream), so that every busy stream's queue is decided HERE: the busy streams are created at
+  //    chosen places of the round robin (main 1, chain[1] 0, xpart[1] 1, aux 2, xcol 3, bchain 1 of q queues: the best of the
+  //    16 xcol x bchain arrangements searched), the streams of layers 2-3 and unused ones fill the gaps.  Identical
+  //    behaviour with and without a process group; 1 % slower forward than the default without one (fork / join).
+  if (!g_stream_pool) {
+    for (int l = 1; l < MATGCN_MAX_LAYERS; ++l) {
+      HIP_OK(hipStreamCreateWithFlags(&g_wf.chain[l], hipStreamNonBlocking));
+      HIP_OK(hipStreamCreateWithFlags(&g_wf.xpart[l], hipStreamNonBlocking));
+    }
+    HIP_OK(hipStreamCreateWithFlags(&g_wf.aux, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&g_wf.xcol, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&g_wf.bchain, hipStreamNonBlocking));
+    g_wf.main = nullptr;
+  } else {
+    int prLeast = 0, prGreatest = 0;
+    HIP_OK(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+    auto make_stream = [&](hipStream_t* st) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prGreatest); };
+    int q = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { const int v = atoi(e); if (v >= 1 && v <= 64) q = v; }
+#ifndef WF_RES
+#define WF_RES {1, 0, 1, 2, 3, 1}
+#endif
+    const int want[6] = WF_RES;        // main, chain[1], xpart[1], aux, xcol, bchain
+    hipStream_t* tgt[6] = {&g_wf.main, &g_wf.chain[1], &g_wf.xpart[1], &g_wf.aux, &g_wf.xcol, &g_wf.bchain};
+    bool made[6] = {false, false, false, false, false, false};
+    hipStream_t* fill[4] = {&g_wf.chain[2], &g_wf.xpart[2], &g_wf.chain[3], &g_wf.xpart[3]};
+    int nFill = 0, left = 6;
+    for (int p = 0; left > 0 && p < 512; ++p) {
+      int pick = -1;
+      for (int i = 0; i < 6; ++i) if (!made[i] && want[i] % q == p % q) { pick = i; break; }
+      if (pick >= 0) { HIP_OK(make_stream(tgt[pick])); made[pick] = true; --left; }
+      else if (nFill < 4) { HIP_OK(make_stream(fill[nFill++])); }
+      else { hipStream_t unused; HIP_OK(make_stream(&unused)); }
+    }
+    while (nFill < 4) HIP_OK(make_stream(fill[nFill++]));
   }
   HIP_OK(hipEventCreateWithFlags(&g_wf.fork, hipEventDisableTiming));
-  HIP_OK(hipStreamCreateWithFlags(&g_wf.aux, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&g_wf.xcol, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&g_wf.bchain, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.mainFork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&g_wf.mainJoin, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.bfork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.bjoin, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxFork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&g_wf.auxDone, hipEventDisableTiming));
-  for (int i = 0; i < 2 * MATGCN_MAX_LAYERS + 3; ++i) HIP_OK(hipEventCreateWithFlags(&g_wf.bail[i], hipEventDisableTiming));
+  for (int i = 0; i < 2 * MATGCN_MAX_LAYERS + 4; ++i) HIP_OK(hipEventCreateWithFlags(&g_wf.bail[i], hipEventDisableTiming));
   for (int l = 0; l < MATGCN_MAX_LAYERS; ++l) {
     HIP_OK(hipEventCreateWithFlags(&g_wf.done[l], hipEventDisableTiming));
     for (int t = 0; t < MAX_STEPS; ++t) {
@@ -476,10 +519,11 @@ void join_library_streams(hipStream_t caller) {
 }
 void join_one_set(Wavefront& W, hipStream_t caller) {
   if (!W.ready) return;
-  hipStream_t all[2 * MATGCN_MAX_LAYERS + 3];
+  hipStream_t all[2 * MATGCN_MAX_LAYERS + 4];
   int n = 0;
   for (int l = 1; l < MATGCN_MAX_LAYERS; ++l) { all[n++] = W.chain[l]; all[n++] = W.xpart[l]; }
   all[n++] = W.aux; all[n++] = W.xcol; all[n++] = W.bchain;
+  if (W.main) all[n++] = W.main;
   for (int i = 0; i < n; ++i) {
     if (all[i] == caller) continue;
     if (hipEventRecord(W.bail[i], all[i]) == hipSuccess) (void)hipStreamWaitEvent(caller, W.bail[i], 0);
@@ -493,6 +537,26 @@ void join_one_set(Wavefront& W, hipStream_t caller) {
     if (rc_ != MATGCN_OK) join_library_streams((hipStream_t)(stream));    \
     return rc_;                                                           \
   } while (0)
+
+// The hot entry points (forward, forward_series, forward_train, backward) run on the library's `main` stream, forked from
+// the caller's stream and joined back into it before they return - success or failure - so the caller still sees one
+// in-order stream - in the own-pool mode (matgcn_set_stream_pool(1)) only.  See wavefront_ready() for why.  (matgcn_set_wavefront(0), the one-stream schedule for kernel timing,
+// keeps the caller's stream.)
+int wavefront_ready();
+extern int g_wavefront_mode;
+template <class Body>
+int on_main_stream(void* callerStream, Body&& body) {
+  if (!g_stream_pool || g_wavefront_mode == 0) return body(callerStream);
+  hipStream_t caller = (hipStream_t)callerStream;
+  RETURN_IF(wavefront_ready());
+  Wavefront& W = g_wf;
+  HIP_OK(hipEventRecord(W.mainFork, caller));
+  HIP_OK(hipStreamWaitEvent(W.main, W.mainFork, 0));
+  const int rc = body((void*)W.main);
+  if (hipEventRecord(W.mainJoin, W.main) == hipSuccess) (void)hipStreamWaitEvent(caller, W.mainJoin, 0);
+  else (void)hipGetLastError();
+  return rc;
+}
 
 #ifdef NODE_LAB_STAMPS   // lab builds only (tools/labs/stamps_r04.py): where the node kernels' in-kernel stamps go
 unsigned int* g_lab_stamps = nullptr;
@@ -1203,6 +1267,14 @@ int matgcn_set_mix_precision(int mode) {
   return prev;
 }
 
+int matgcn_set_stream_pool(int own) {
+  for (int d = 0; d < MAX_DEVICES; ++d)
+    for (int set = 0; set < 2; ++set)
+      if (g_wfs[d][set].ready) return own ? (g_stream_pool ? MATGCN_OK : MATGCN_ERR_BAD_ARG) : (g_stream_pool ? MATGCN_ERR_BAD_ARG : MATGCN_OK);
+  g_stream_pool = own ? 1 : 0;
+  return MATGCN_OK;
+}
+
 int matgcn_set_wavefront(int mode) {
   const int prev = g_wavefront_mode;
   g_wavefront_mode = (mode == 1 || mode == 2) ? mode : (mode != 0 ? 1 : 0);
@@ -1509,8 +1581,8 @@ static int forward_split(const matgcn_dims* dims, const matgcn_params* params, c
   return MATGCN_OK;
 }
 
-int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
-                   const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+static int forward_entry(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                         const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!prepared || !X || !out) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream, false));   // chains wait per layer
@@ -1525,6 +1597,13 @@ int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const v
   return forward_once(c, X, nullptr, 0, nullptr, nullptr, h0, out);
 }
 
+int matgcn_forward(const matgcn_dims* dims, const matgcn_params* params, const void* prepared, const float* X,
+                   const float* h0, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return on_main_stream(stream, [&](void* s) {
+    return forward_entry(dims, params, prepared, X, h0, out, workspace, workspace_bytes, s);
+  });
+}
+
 // the host-visible part of the series range contract: no window row may start before the series
 static int check_series(const matgcn_dims* dims, const float* series, int64_t series_steps, const int32_t* label_start,
                  const int32_t* rel_steps) {
@@ -1536,10 +1615,10 @@ static int check_series(const matgcn_dims* dims, const float* series, int64_t se
   return MATGCN_OK;
 }
 
-int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
-                          const float* series, int64_t series_steps, const int32_t* label_start,
-                          const int32_t* rel_steps, const float* h0, float* out, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+static int forward_series_entry(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                                const float* series, int64_t series_steps, const int32_t* label_start,
+                                const int32_t* rel_steps, const float* h0, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   if (!prepared || !series || !label_start || !rel_steps || !out) return MATGCN_ERR_NULL;
   Ctx c;
   RETURN_IF(make_ctx(&c, dims, params, prepared, workspace, workspace_bytes, stream, false));   // chains wait per layer
@@ -1553,6 +1632,16 @@ int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, 
   if (done) return MATGCN_OK;
   MixPrecisionScope mixScope(true);
   return forward_once(c, nullptr, series, series_steps, label_start, rel_steps, h0, out);
+}
+
+int matgcn_forward_series(const matgcn_dims* dims, const matgcn_params* params, const void* prepared,
+                          const float* series, int64_t series_steps, const int32_t* label_start,
+                          const int32_t* rel_steps, const float* h0, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  return on_main_stream(stream, [&](void* s) {
+    return forward_series_entry(dims, params, prepared, series, series_steps, label_start, rel_steps, h0, out, workspace,
+                                workspace_bytes, s);
+  });
 }
 
 int matgcn_fuse_heads(const matgcn_dims* dims, const matgcn_params* params, const float* X, float* x0,

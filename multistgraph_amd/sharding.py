@@ -17,6 +17,16 @@ import torch
 import torch.distributed as dist
 
 
+def use_own_stream_pool() -> None:
+    """For data-parallel jobs: call once per process BEFORE the first forward of the HIP path.  The library then keeps its
+    streams in a hardware-queue pool of their own (highest stream priority) and runs its hot entry points on a library
+    stream instead of the caller's, so that an RCCL communicator's streams cannot push two of the path's chains onto one
+    hardware queue (forward 8.0 instead of 6.8 ms at the headline shape; ``matgcn_set_stream_pool`` in include/matgcn.h,
+    profiles/r04_rccl_queues_lab.log).  Raises if the streams already exist in the other mode."""
+    from . import _lib
+    _lib.check(_lib.load().matgcn_set_stream_pool(1), "matgcn_set_stream_pool")
+
+
 def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     """[begin, end) rows of the global batch owned by ``rank``: contiguous, sizes differ by at most one
     (the first ``global_batch % world`` ranks take the extra row)."""

@@ -126,7 +126,7 @@ def test_library_exports_every_declared_symbol(lib_built):
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym)
-    assert lib.matgcn_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.matgcn_abi_version() == _lib.ABI_VERSION == 11
     assert lib.matgcn_error_string(-3) == b"configuration not supported by this build"
 
 
@@ -255,6 +255,7 @@ int main(void) {
   if (matgcn_prepared_bytes(&d, NULL) != MATGCN_ERR_NULL) return 3;
   if (!matgcn_error_string(MATGCN_ERR_BAD_ARG)) return 4;
   if (matgcn_set_batch_split(0) != 0 || matgcn_set_mix_precision(0) != 0) return 5;
+  if (matgcn_set_stream_pool(0) != MATGCN_OK) return 6;                     /* the default mode, before any stream exists */
   printf("abi %d ok\\n", matgcn_abi_version());
   return 0;
 }
@@ -266,7 +267,7 @@ int main(void) {
                     "-L", libdir, "-lmatgcn", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env)
-    assert "abi 10 ok" in out.stdout
+    assert "abi 11 ok" in out.stdout
 
 
 def test_bench_flop_models_are_consistent():

@@ -235,13 +235,15 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
     the GPU.  With one rank the mean is the identity: gradients must come back bit-identical."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from helpers import Case
+    from helpers import Case, max_norm_err
     from multistgraph_amd.model import MultiATGCN
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # what a data-parallel job does before its first forward: the path's streams in a hardware-queue pool of their own
+    sh.use_own_stream_pool()
     try:
         for name, has_bucket, has_rest in (("tiny_multi_uni_c2_static", True, True), ("hid32_multi_uni_c2", False, True),
                                            ("tiny_multi_uni_c2", True, False)):
@@ -253,6 +255,13 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
             opt = torch.optim.Adam(model.parameters(), lr=1e-3)
             x = torch.from_numpy(c.x).to(dev)
             y = torch.from_numpy(c.y).to(dev)
+            # the own-pool mode moves the work onto a library stream: the results must still be the reference's
+            model.eval()
+            with torch.no_grad():
+                got = model.predict({"X": x}).cpu().numpy()
+            if c.static_dim == 0:     # (the static-feature case draws its PCA basis at construction: no fixed prediction)
+                assert max_norm_err(got, c.gold["pred"]) <= 1e-4, name
+            model.train()
             for _ in range(2):
                 opt.zero_grad()
                 loss = model.calculate_loss({"X": x, "y": y})
@@ -265,6 +274,9 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
                         assert torch.equal(p.grad, before[k]), (name, k)
                 opt.step()
                 assert sh.replicas_in_sync(model.parameters(), device=dev), name
+        # the pool mode cannot be left once the streams exist; asking for the mode in use is fine
+        from multistgraph_amd import _lib
+        assert _lib.load().matgcn_set_stream_pool(1) == 0 and _lib.load().matgcn_set_stream_pool(0) != 0
         # the bench's own aggregate over RCCL: barrier + MAX over ranks of the elapsed time, SUM of the units
         total, slowest = sh.job_throughput(1000.0, 0.5, device=dev)
         assert abs(total - 2000.0) < 1e-6 and abs(slowest - 0.5) < 1e-9
