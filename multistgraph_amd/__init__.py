@@ -1,4 +1,4 @@
 """MI355X-native Multi-ATGCN hot path (see README.md / DESIGN.md).
 
-Data-parallel jobs (torch.distributed on the "nccl" = RCCL backend) should export GPU_MAX_HW_QUEUES=8 before the
-process starts: INTEGRATION.md section 5, profiles/r04_rccl_queues_lab.log."""
+Data-parallel jobs (torch.distributed on the "nccl" = RCCL backend) call sharding.use_own_stream_pool() before their first
+forward: INTEGRATION.md section 5, profiles/r04_rccl_queues_lab.log."""

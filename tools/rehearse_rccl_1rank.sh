@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py's multi-rank branch with the ONE rank a one-GPU box has, over the real backend (nccl = RCCL): process group on
 # the device, barriers, the MAX / SUM reductions of the timing, the flat-bucket gradient all-reduce of the training step -
-# RCCL calls on GPU tensors instead of the gloo rehearsal's; not a scaling number (n_gpus = 1)
+# RCCL calls on GPU tensors instead of the gloo rehearsal's, the library streams in their own queue pool; not a scaling number (n_gpus = 1)
 set -o pipefail
 mkdir -p gpurun_out/rehearse
 MATGCN_BENCH_FORCE_DIST=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
