@@ -34,6 +34,8 @@ def main():
         w["batch"] = args.batch
     model, df, cfg = bench.build_model(w, dev, 0)
     model.cache_prepared = bool(args.cache_prepared)
+    if os.environ.get("MATGCN_POOL") == "1":      # the data-parallel jobs' stream mode (matgcn_set_stream_pool) in a single process
+        _lib.check(_lib.load().matgcn_set_stream_pool(1), "matgcn_set_stream_pool")
     if args.serial:
         _lib.load().matgcn_set_wavefront(0)
     if args.token:
