@@ -364,7 +364,8 @@ int matgcn_set_wavefront(int enabled);
  * matgcn_forward / _forward_series / _forward_train / _backward on a library stream forked from and joined back into the
  * caller's: the same timings with and without a process group, about 1 % behind the default without one.  Must be called
  * before the first of those entry points creates the streams (MATGCN_ERR_BAD_ARG afterwards, unless the mode asked for is
- * the one in use).  Results are bit-identical in both modes. */
+ * the one in use).  A scheduling change only: the forward's results are bit-identical in both modes, gradients agree up to the
+ * order of the backward's atomic accumulations (as two runs in one mode do). */
 int matgcn_set_stream_pool(int own);
 
 /* Lazy prepare.  By default `prepared` is complete, in stream order, when matgcn_prepare returns.  With

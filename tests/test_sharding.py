@@ -293,3 +293,55 @@ def test_gradient_exchange_over_rccl_with_the_one_rank_a_box_has(tmp_path):
     device, the layout vote and both gradient all-reduces as RCCL collectives on GPU tensors, the checksum on the GPU"""
     mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / "rccl_ok0").exists()
+
+
+def _mode_worker(rank, pool, out_dir):
+    """one process = one stream mode (it cannot be changed once the streams exist): prediction and gradients of a golden
+    case, written out for a bitwise comparison between the modes"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import Case
+    from multistgraph_amd.model import MultiATGCN
+    from multistgraph_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if pool:
+        sh.use_own_stream_pool()
+    out = {}
+    for name in ("tiny_multi_uni_c2", "tiny_od_non_c3"):
+        c = Case(name)
+        torch.manual_seed(3)
+        model = MultiATGCN(c.config("cuda:0"), c.data_feature).to(dev)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in c.state.items()})
+        x = torch.from_numpy(c.x).to(dev)
+        y = torch.from_numpy(c.y).to(dev)
+        model.eval()
+        with torch.no_grad():
+            out[name + "/pred"] = model.predict({"X": x}).cpu().numpy()
+        loss = model.calculate_loss({"X": x, "y": y})     # eval mode: no dropout, the training forward and the backward
+        loss.backward()
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out[name + "/grad/" + k] = p.grad.detach().cpu().numpy()
+    assert _lib.load().matgcn_set_stream_pool(1 if pool else 0) == 0
+    np.savez(os.path.join(out_dir, "mode%d.npz" % pool), **out)
+
+
+@pytest.mark.gpu
+def test_own_stream_pool_gives_the_same_bits(tmp_path):
+    """matgcn_set_stream_pool(1) moves the hot entry points onto a library stream and the library's streams into a queue pool
+    of their own: a scheduling change only - predictions bit-identical to the default mode's, gradients equal up to the order
+    of their atomic accumulations"""
+    for pool in (0, 1):
+        mp.spawn(_mode_worker, args=(pool, str(tmp_path)), nprocs=1, join=True)
+    a, b = np.load(tmp_path / "mode0.npz"), np.load(tmp_path / "mode1.npz")
+    assert sorted(a.files) == sorted(b.files) and len(a.files) > 10
+    for k in a.files:
+        if k.endswith("/pred"):
+            assert np.array_equal(a[k], b[k]), k          # the forward: bit for bit
+        else:
+            # the backward accumulates some gradients with atomic adds across its streams (run-to-run differences in the
+            # last bits in EITHER mode): the modes must agree to that level
+            scale = float(np.abs(a[k]).max()) + 1e-30
+            assert float(np.abs(a[k] - b[k]).max()) <= 2e-6 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
